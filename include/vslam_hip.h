@@ -1,0 +1,192 @@
+/*
+ * vslam_hip.h -- C ABI of the MI355X (gfx950) hot path of scomup/visual_slam:
+ * bundle-adjustment linearisation + per-landmark Schur elimination + LM, and the 256-d SuperPoint
+ * descriptor matchers.  Plain pointers and sizes only; every pointer argument may be a host or a
+ * device pointer unless stated otherwise (copies use hipMemcpyDefault).  All entry points return
+ * VS_OK (0) or a negative vs_status; vs_last_error_string() describes the last failure on the
+ * calling thread.  Nothing throws or exits across this boundary.  A handle is not thread-safe: use
+ * one handle per (thread, GPU).  Calls are stream-ordered on the handle's stream and block until
+ * their host-visible outputs are complete.
+ *
+ * Reference paths cited below are relative to the reference tree (scomup/visual_slam).
+ */
+#ifndef VSLAM_HIP_H_
+#define VSLAM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    VS_OK = 0,
+    VS_ERR_INVALID = -1,      /* bad argument (null pointer, index out of range, duplicate edge) */
+    VS_ERR_HIP = -2,          /* a HIP runtime call failed (no device, launch failure, ...) */
+    VS_ERR_NOMEM = -3,
+    VS_ERR_STATE = -4,        /* call order violated (e.g. solve before observations are set) */
+    VS_ERR_NUMERIC = -5,      /* reduced camera system not positive definite */
+    VS_ERR_UNSUPPORTED = -6   /* size beyond what this build's reduced-system solver handles */
+} vs_status;
+
+const char *vs_last_error_string(void);
+/* Library version string and the GPU architecture the kernels were compiled for ("gfx950"). */
+const char *vs_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Bundle adjustment.  Replaces what the reference does between Optimizer::addReprojectionEdges
+ * and ceres::Solve (src/core/optimizer.cc:60-145, src/core/tracking.cc:97-110, 139-152) with the
+ * residual functor of src/core/reprojection_error.h:22-51.
+ * Parameter layout: camera c = translation t[3c..3c+2] and (roll,pitch,yaw) rpy[3c..3c+2]
+ * (PoseData, src/core/optimizer.h:17-22); point j = xyz[3j..3j+2] (optimizer.h:42).
+ * Camera-block parameter order everywhere: (t0,t1,t2,roll,pitch,yaw).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vs_ba *vs_ba_handle;
+
+typedef struct {
+    int32_t max_num_iterations;        /* tracking.cc:102 sets 100 */
+    double initial_trust_region_radius;/* Ceres default 1e4 */
+    double max_trust_region_radius;    /* 1e16 */
+    double min_trust_region_radius;    /* 1e-32 */
+    double min_relative_decrease;      /* 1e-3 */
+    double min_lm_diagonal;            /* 1e-6 */
+    double max_lm_diagonal;            /* 1e32 */
+    double function_tolerance;         /* 1e-6 */
+    double gradient_tolerance;         /* 1e-10 */
+    double parameter_tolerance;        /* 1e-8 */
+    int32_t max_consecutive_invalid_steps; /* 5 */
+} vs_lm_options;
+
+typedef struct {
+    int32_t iterations;
+    int32_t successful_steps;
+    int32_t termination;               /* 0 convergence, 1 no convergence, 2 failure */
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+} vs_lm_summary;
+
+/* Fills *o with the options the reference runs with: max_num_iterations = 100
+ * (tracking.cc:102,144), everything else the Ceres defaults ceres::Solver::Options() carries. */
+void vs_lm_default_options(vs_lm_options *o);
+
+/* Creates a problem of fixed size on the current HIP device.  fx,fy,cx,cy: the four entries the
+ * reference puts into K (tracking.cc:58-62), widened from float as reprojection_error.h:44 does. */
+int vs_ba_create(vs_ba_handle *h, int32_t n_cameras, int32_t n_points, int64_t n_observations,
+                 double fx, double fy, double cx, double cy);
+int vs_ba_destroy(vs_ba_handle h);
+/* hipStream_t to launch on (default: the null stream). */
+int vs_ba_set_stream(vs_ba_handle h, void *hip_stream);
+
+/* Optimizer::addPose (optimizer.cc:14-17): t, rpy are n_cameras x 3 doubles. */
+int vs_ba_set_cameras(vs_ba_handle h, const double *t, const double *rpy);
+/* Optimizer::addPoints (optimizer.cc:19-28): n_points x 3 doubles. */
+int vs_ba_set_points(vs_ba_handle h, const double *xyz);
+/* The residual blocks addReprojectionEdges adds (optimizer.cc:102-143), one per entry, in the
+ * caller's order: camera index, point index, keypoint (u,v).  HOST pointers.  An edge may appear
+ * at most once per (camera, point).  Builds the landmark-major / camera-major / camera-pair
+ * index structures used by the kernels; call again only when the edge set changes. */
+int vs_ba_set_observations(vs_ba_handle h, const int32_t *cam, const int32_t *pt, const double *uv);
+/* Multi-GPU: as vs_ba_set_observations, but this handle linearises only the landmarks of shard
+ * `rank` of `world` (contiguous landmark ranges balanced by observation count) while keeping the
+ * global camera-pair block pattern, so vs_ba_reduce_buffer() has identical layout on every rank. */
+int vs_ba_set_observations_sharded(vs_ba_handle h, const int32_t *cam, const int32_t *pt,
+                                   const double *uv, int32_t rank, int32_t world);
+/* SetParameterBlockConstant on every point (fix_points != 0; optimizer.cc:134-137, the
+ * fix_camera_or_point = true mode of Tracking::solveCamera).  Cameras are always free
+ * (the code freezing them is commented out, optimizer.cc:90-100). */
+int vs_ba_set_fixed(vs_ba_handle h, int32_t fix_points);
+/* HuberLoss(a) on the FIRST observation only, none on the rest (optimizer.cc:69,128);
+ * a <= 0 disables it (default). */
+int vs_ba_set_huber_first(vs_ba_handle h, double a);
+
+/* (a) residual + Jacobian evaluation at the current parameters.  Any output may be NULL.
+ * cost = 0.5 * sum rho(|r|^2); res: n_obs x 2; Jc: n_obs x 12 (2x6 row-major); Jp: n_obs x 6
+ * (2x3 row-major), all in the caller's observation order, loss-corrected like Ceres does. */
+int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double *Jp);
+
+/* (a)+(b) fused: linearise at the current parameters and form the reduced camera system
+ *   S = U + diag(damp_c) - sum_j W_j (V_j + diag(damp_p_j))^-1 W_j^T,
+ *   rhs = -g_c + sum_j W_j (V_j + diag(damp_p_j))^-1 g_p_j
+ * on the device (J is never materialised).  damp_c: 6*n_cameras, damp_p: 3*n_points, or NULL = 0.
+ * This is the step the throughput metric times.  Results stay on the device. */
+int vs_ba_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p);
+/* Stored upper-triangular 6x6 blocks of S: the n_cameras diagonal blocks first, then the
+ * off-diagonal blocks (row < col) sorted by (row, col).  Pattern is fixed by the edge set. */
+int vs_ba_block_count(vs_ba_handle h, int64_t *n_blocks);
+int vs_ba_block_index(vs_ba_handle h, int32_t *block_row, int32_t *block_col);
+/* Copies out what the last vs_ba_linearize produced.  S_blocks: n_blocks x 36 (6x6 row-major);
+ * rhs: 6*n_cameras; cost: scalar.  Any may be NULL. */
+int vs_ba_get_reduced_system(vs_ba_handle h, double *S_blocks, double *rhs, double *cost);
+/* Per-landmark products of the last vs_ba_linearize: Vinv n_points x 6 (xx,xy,xz,yy,yz,zz of the
+ * damped inverse), gp n_points x 3.  Any may be NULL. */
+int vs_ba_get_landmark_blocks(vs_ba_handle h, double *Vinv6, double *gp);
+/* Device buffer holding [S diagonal blocks | S off-diagonal blocks | rhs | diag(U) | g_c | cost]
+ * as doubles, the quantity landmark shards sum across GPUs (all-reduce) before solving. */
+int vs_ba_reduce_buffer(vs_ba_handle h, void **device_ptr, int64_t *n_doubles);
+
+/* One Levenberg-Marquardt step at the current parameters with the given trust-region radius:
+ * Jacobi scaling (fixed at the handle's first step), LM diagonal, Schur, reduced solve,
+ * back-substitution.  dcam: n_cameras x 6, dpt: n_points x 3 (zeros when points are fixed),
+ * model_cost_change = -(J d)^T (r + J d / 2).  Parameters are not modified. */
+int vs_ba_lm_step(vs_ba_handle h, double radius, double *dcam, double *dpt,
+                  double *model_cost_change);
+/* ceres::Solve replacement (tracking.cc:110,152): runs LM to termination and updates the
+ * handle's parameters in place. */
+int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summary);
+/* Multi-GPU hook: called by vs_ba_lm_step / vs_ba_solve after the local reduced system is formed
+ * and before damping and solving; must sum `n` doubles at device pointer `buf` across ranks. */
+typedef int (*vs_allreduce_fn)(void *user, void *device_buf, int64_t n_doubles);
+int vs_ba_set_allreduce(vs_ba_handle h, vs_allreduce_fn fn, void *user);
+
+/* Optimizer::getPose / getPoints payloads (optimizer.cc:51-59,187-190). */
+int vs_ba_get_cameras(vs_ba_handle h, double *t, double *rpy);
+int vs_ba_get_points(vs_ba_handle h, double *xyz);
+
+/* ------------------------------------------------------------------------------------------
+ * Descriptor matching.  Replaces SuperpointFrontend::twoWayMatching
+ * (src/core/superpoint_frontend.cc:163-211) and getStereoMatching (:110-161):
+ *   d(i,j) = sqrtf(2 - 2*clamp((float)dot(desc0_i, desc1_j), -1, 1)), dot accumulated in double;
+ *   idx0[i] = first argmin_j, idx1[j] = first argmin_i; keep (i, idx0[i], d) iff
+ *   idx1[idx0[i]] == i and d < nn_thresh; output ordered by i.
+ * Descriptors are n x 256 row-major fp32 (superpoint_frontend.cc:97-107).
+ * ratio < 1 additionally requires d < ratio * (second smallest d of row i); ratio >= 1 = off
+ * (the reference has no ratio test).
+ * ------------------------------------------------------------------------------------------ */
+#define VS_DESC_DIM 256
+
+typedef struct vs_matcher *vs_matcher_handle;
+
+/* Batched matcher with device-resident buffers for up to max_pairs frame pairs of up to
+ * max_n0 x max_n1 descriptors each. */
+int vs_matcher_create(vs_matcher_handle *m, int32_t max_pairs, int32_t max_n0, int32_t max_n1);
+int vs_matcher_destroy(vs_matcher_handle m);
+int vs_matcher_set_stream(vs_matcher_handle m, void *hip_stream);
+/* Loads pair `pair`.  xy0/xy1 (n x 2 int32 pixel coordinates, cv::Point) may both be NULL
+ * (twoWayMatching) or both non-NULL (getStereoMatching's mask: entries with |y0-y1| > 20 or
+ * x0 < x1 keep distance 1.0 and still compete, superpoint_frontend.cc:117,126-129). */
+int vs_matcher_set_pair(vs_matcher_handle m, int32_t pair, const float *desc0, int32_t n0,
+                        const float *desc1, int32_t n1, const int32_t *xy0, const int32_t *xy1);
+/* Matches pairs [0, n_pairs) on the device.  Results stay on the device. */
+int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float ratio);
+/* Copies out pair `pair`'s matches (each array sized >= n0 of that pair). */
+int vs_matcher_get_matches(vs_matcher_handle m, int32_t pair, int32_t *out_i, int32_t *out_j,
+                           float *out_d, int32_t *out_n);
+/* Row / column nearest neighbours of the last run (idx0: n0, idx1: n1). */
+int vs_matcher_get_nn(vs_matcher_handle m, int32_t pair, int32_t *idx0, int32_t *idx1);
+/* Number of rows+columns whose nearest neighbour had to be re-decided by the exact fp64 scan
+ * in the last run (diagnostic). */
+int vs_matcher_get_rescans(vs_matcher_handle m, int64_t *n_rescanned);
+
+/* One-shot forms with the reference's call shape (host or device pointers). */
+int vs_match_two_way(const float *desc0, int32_t n0, const float *desc1, int32_t n1,
+                     float nn_thresh, float ratio, int32_t *out_i, int32_t *out_j, float *out_d,
+                     int32_t *out_n);
+int vs_match_stereo(const float *desc0, const int32_t *xy0, int32_t n0, const float *desc1,
+                    const int32_t *xy1, int32_t n1, float nn_thresh, float ratio, int32_t *out_i,
+                    int32_t *out_j, float *out_d, int32_t *out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_HIP_H_ */

@@ -1,0 +1,226 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under visual_slam_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_fp = C.POINTER(C.c_float)
+c_ip = C.POINTER(C.c_int32)
+c_lp = C.POINTER(C.c_int64)
+c_bp = C.POINTER(C.c_uint8)
+
+DEFAULT_OPTS = np.array([100, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8, 5],
+                        dtype=np.float64)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.vo_build_edges.restype = C.c_int64
+        _LIB.vo_desc_distance.restype = C.c_float
+    return _LIB
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(c_dp)
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(c_fp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(c_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def K4(fx=170.5, fy=170.5, cx=191.5, cy=103.4):
+    """Intrinsics as the reference holds them: floats widened to double (config.yaml:12-15)."""
+    return np.array([np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy)],
+                    dtype=np.float64)
+
+
+def residual(point, uv, t, rpy, K):
+    out = np.zeros(2)
+    lib().vo_residual(_d(_f64(point)), _d(_f64(uv)), _d(_f64(t)), _d(_f64(rpy)), _d(_f64(K)), _d(out))
+    return out
+
+
+def jacobian(point, t, rpy, K):
+    Jp, Jt, Jr = np.zeros((2, 3)), np.zeros((2, 3)), np.zeros((2, 3))
+    lib().vo_jacobian(_d(_f64(point)), _d(_f64(t)), _d(_f64(rpy)), _d(_f64(K)), _d(Jp), _d(Jt), _d(Jr))
+    return Jp, Jt, Jr
+
+
+def build_edges(tracks, keys):
+    """tracks: (n_frames, n_points) int; keys: list of (n_k, 2) int arrays per frame."""
+    tracks = _i32(tracks)
+    nf, npnt = tracks.shape
+    ptr = np.zeros(nf + 1, dtype=np.int64)
+    for f, k in enumerate(keys):
+        ptr[f + 1] = ptr[f] + len(k)
+    xy = _i32(np.concatenate([np.asarray(k).reshape(-1, 2) for k in keys], axis=0)) if nf else np.zeros((0, 2), np.int32)
+    n = lib().vo_build_edges(nf, npnt, _i(tracks), ptr.ctypes.data_as(c_lp), _i(xy), None, None, None)
+    if n < 0:
+        raise ValueError("no points")
+    cam = np.zeros(n, np.int32); pt = np.zeros(n, np.int32); uv = np.zeros((n, 2))
+    if n:
+        lib().vo_build_edges(nf, npnt, _i(tracks), ptr.ctypes.data_as(c_lp), _i(xy), _i(cam), _i(pt), _d(uv))
+    return cam, pt, uv
+
+
+class Problem:
+    """Plain container of a BA problem in the oracle's flat layout."""
+
+    def __init__(self, K, t, rpy, pts, cam, pt, uv, huber_a=0.0, fix_points=False):
+        self.K = _f64(K); self.t = _f64(t).reshape(-1, 3).copy(); self.rpy = _f64(rpy).reshape(-1, 3).copy()
+        self.pts = _f64(pts).reshape(-1, 3).copy()
+        self.cam = _i32(cam); self.pt = _i32(pt); self.uv = _f64(uv).reshape(-1, 2)
+        self.huber_a = float(huber_a); self.fix_points = bool(fix_points)
+        self.Nc, self.Np, self.No = len(self.t), len(self.pts), len(self.cam)
+
+    def _args(self):
+        return (self.Nc, self.Np, C.c_int64(self.No), _d(self.K), _d(self.t), _d(self.rpy),
+                _d(self.pts), _i(self.cam), _i(self.pt), _d(self.uv), C.c_double(self.huber_a))
+
+    def evaluate(self, jac=True):
+        cost = C.c_double(0)
+        res = np.zeros((self.No, 2))
+        Jc = np.zeros((self.No, 2, 6)) if jac else None
+        Jp = np.zeros((self.No, 2, 3)) if jac else None
+        lib().vo_evaluate(*self._args(), C.byref(cost), _d(res), _d(Jc), _d(Jp))
+        return cost.value, res, Jc, Jp
+
+    def cost(self):
+        cost = C.c_double(0)
+        lib().vo_evaluate(*self._args(), C.byref(cost), None, None, None)
+        return cost.value
+
+    def schur(self, dc=None, dp=None, want_S=True):
+        n = 6 * self.Nc
+        S = np.zeros((n, n)) if want_S else None
+        rhs = np.zeros(n); U = np.zeros((self.Nc, 6, 6)); gc = np.zeros(n)
+        Vinv = np.zeros((self.Np, 3, 3)); gp = np.zeros((self.Np, 3)); V = np.zeros((self.Np, 3, 3))
+        dc = None if dc is None else _f64(dc)
+        dp = None if dp is None else _f64(dp)
+        lib().vo_schur(*self._args(), int(self.fix_points), _d(dc), _d(dp), _d(S), _d(rhs), _d(U),
+                       _d(gc), _d(Vinv), _d(gp), _d(V))
+        return dict(S=S, rhs=rhs, U=U, gc=gc, Vinv=Vinv, gp=gp, V=V)
+
+    def normal_dense(self):
+        n = 6 * self.Nc + (0 if self.fix_points else 3 * self.Np)
+        H = np.zeros((n, n)); g = np.zeros(n)
+        lib().vo_normal_dense(*self._args(), int(self.fix_points), _d(H), _d(g))
+        return H, g
+
+    def lm_step(self, radius=1e4, scale_c=None, scale_p=None, min_d=1e-6, max_d=1e32):
+        sc = np.zeros(6 * self.Nc) if scale_c is None else _f64(scale_c).copy()
+        sp = np.zeros(max(3 * self.Np, 1)) if scale_p is None else _f64(scale_p).copy()
+        dcam = np.zeros((self.Nc, 6)); dpt = np.zeros((self.Np, 3)); mcc = C.c_double(0)
+        rc = lib().vo_lm_step(*self._args(), int(self.fix_points), C.c_double(radius),
+                              C.c_double(min_d), C.c_double(max_d), _d(sc), _d(sp), _d(dcam),
+                              _d(dpt), C.byref(mcc))
+        return rc, dcam, dpt, mcc.value, sc, sp[:3 * self.Np]
+
+    def solve(self, opts=None):
+        opts = DEFAULT_OPTS if opts is None else _f64(opts)
+        summary = np.zeros(6)
+        lib().vo_solve(self.Nc, self.Np, C.c_int64(self.No), _d(self.K), _d(self.t), _d(self.rpy),
+                       _d(self.pts), _i(self.cam), _i(self.pt), _d(self.uv),
+                       C.c_double(self.huber_a), int(self.fix_points), _d(opts), _d(summary))
+        return dict(iterations=int(summary[0]), initial_cost=summary[1], final_cost=summary[2],
+                    termination=int(summary[3]), successful_steps=int(summary[4]),
+                    radius=summary[5])
+
+
+def quat_to_euler012(q):
+    e = np.zeros(3)
+    lib().vo_quat_to_euler012(_d(_f64(q)), _d(e))
+    return e
+
+
+def rpy_to_quat(rpy):
+    q = np.zeros(4)
+    lib().vo_rpy_to_quat(_d(_f64(rpy)), _d(q))
+    return q
+
+
+def desc_distance(a, b):
+    return float(lib().vo_desc_distance(_f(_f32(a)), _f(_f32(b))))
+
+
+def distance_matrix(d0, d1, xy0=None, xy1=None):
+    d0, d1 = _f32(d0), _f32(d1)
+    out = np.zeros((len(d0), len(d1)), np.float32)
+    xy0 = None if xy0 is None else _i32(xy0)
+    xy1 = None if xy1 is None else _i32(xy1)
+    lib().vo_distance_matrix(_f(d0), len(d0), _f(d1), len(d1), _i(xy0), _i(xy1), _f(out))
+    return out
+
+
+def _matches(fn, n0, *args):
+    oi = np.zeros(max(n0, 1), np.int32); oj = np.zeros(max(n0, 1), np.int32); od = np.zeros(max(n0, 1), np.float32)
+    n = fn(*args, _i(oi), _i(oj), _f(od))
+    return oi[:n].copy(), oj[:n].copy(), od[:n].copy()
+
+
+def two_way_matching(d0, d1, nn_thresh=2.0, ratio=1.0):
+    d0, d1 = _f32(d0).reshape(-1, 256), _f32(d1).reshape(-1, 256)
+    return _matches(lib().vo_two_way_matching, len(d0), _f(d0), len(d0), _f(d1), len(d1),
+                    C.c_float(nn_thresh), C.c_float(ratio))
+
+
+def stereo_matching(d0, xy0, d1, xy1, nn_thresh=2.0, ratio=1.0):
+    d0, d1 = _f32(d0).reshape(-1, 256), _f32(d1).reshape(-1, 256)
+    xy0, xy1 = _i32(xy0), _i32(xy1)
+    return _matches(lib().vo_stereo_matching, len(d0), _f(d0), _i(xy0), len(d0), _f(d1), _i(xy1),
+                    len(d1), C.c_float(nn_thresh), C.c_float(ratio))
+
+
+def stereo_one_way(d0, xy0, d1, xy1):
+    d0, d1 = _f32(d0).reshape(-1, 256), _f32(d1).reshape(-1, 256)
+    xy0, xy1 = _i32(xy0), _i32(xy1)
+    loc = np.zeros(len(d0), np.int32); mind = np.zeros(len(d0), np.float32)
+    lib().vo_stereo_one_way(_f(d0), _i(xy0), len(d0), _f(d1), _i(xy1), len(d1), _i(loc), _f(mind))
+    return loc, mind
+
+
+def search_projection(reproj_xy, tp_desc, key_xy, key_desc, width2, height2, radius=30.0,
+                      accept=0.8, claimed=None):
+    reproj_xy, key_xy = _i32(reproj_xy), _i32(key_xy)
+    tp_desc, key_desc = _f32(tp_desc).reshape(-1, 256), _f32(key_desc).reshape(-1, 256)
+    claimed = np.zeros(len(key_xy), np.uint8) if claimed is None else np.ascontiguousarray(claimed, np.uint8).copy()
+    tracks = np.zeros(len(reproj_xy), np.int32)
+    lib().vo_search_projection(_i(reproj_xy), _f(tp_desc), len(reproj_xy), _i(key_xy), _f(key_desc),
+                               len(key_xy), C.c_float(width2), C.c_float(height2),
+                               C.c_float(radius), C.c_double(accept),
+                               claimed.ctypes.data_as(c_bp), _i(tracks))
+    return tracks, claimed

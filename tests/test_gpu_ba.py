@@ -1,0 +1,254 @@
+"""GPU parity tests of the bundle-adjustment path: HIP kernels (through the C ABI) vs the CPU
+oracle on the same seeded inputs, and vs the committed golden fixtures.
+
+Tolerances: the kernels compute in fp64 like the reference, so residuals, Jacobians and Schur
+blocks are compared at 1e-9 relative (north-star bound: 1e-5); LM steps at 1e-6 relative because
+the gauge-free reduced system amplifies rounding differences."""
+import numpy as np
+import pytest
+
+from visual_slam_amd import synth
+from visual_slam_amd.ba import BAProblem
+from visual_slam_amd._lib import VslamError
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def both(orc, sc, t=None, rpy=None, pts=None, **kw):
+    t = sc.t0 if t is None else t
+    rpy = sc.rpy0 if rpy is None else rpy
+    pts = sc.pts0 if pts is None else pts
+    ref = orc.Problem(sc.K, t, rpy, pts, sc.cam, sc.pt, sc.uv, **kw)
+    gpu = BAProblem.from_arrays(sc.K, t, rpy, pts, sc.cam, sc.pt, sc.uv, **kw)
+    return ref, gpu
+
+
+def dense_from(gpu):
+    return gpu.reduced_system_dense()
+
+
+@pytest.fixture(scope="module")
+def shuffled_c1():
+    sc = synth.make_ba_config("c1", seed=3)
+    perm = np.random.default_rng(0).permutation(sc.No)     # caller order != landmark order
+    sc.cam, sc.pt, sc.uv = sc.cam[perm], sc.pt[perm], sc.uv[perm]
+    return sc
+
+
+def test_evaluate_matches_golden_and_oracle(orc, golden_dir, shuffled_c1):
+    g = np.load(golden_dir + "/ba_small.npz")
+    gpu = BAProblem.from_arrays(g["K"], g["t"], g["rpy"], g["pts"], g["cam"], g["pt"], g["uv"])
+    cost, res, Jc, Jp = gpu.evaluate()
+    assert abs(cost - float(g["cost"])) < 1e-11 * float(g["cost"])
+    assert np.abs(res - g["res"]).max() < 1e-10
+    assert rel(Jc, g["Jc"]) < 1e-11 and rel(Jp, g["Jp"]) < 1e-11
+    ref, gpu = both(orc, shuffled_c1)
+    c0, r0, Jc0, Jp0 = ref.evaluate()
+    c1, r1, Jc1, Jp1 = gpu.evaluate()
+    assert abs(c1 - c0) < 1e-11 * c0
+    assert np.abs(r1 - r0).max() < 1e-9
+    assert rel(Jc1, Jc0) < 1e-11 and rel(Jp1, Jp0) < 1e-11
+
+
+def test_schur_blocks_match_golden(golden_dir):
+    g = np.load(golden_dir + "/ba_small.npz")
+    gpu = BAProblem.from_arrays(g["K"], g["t"], g["rpy"], g["pts"], g["cam"], g["pt"], g["uv"])
+    nc = 6 * gpu.Nc
+    gpu.linearize(g["lam"][:nc], g["lam"][nc:])
+    S, rhs, cost = dense_from(gpu)
+    assert rel(S, g["S"]) < 1e-10 and rel(rhs, g["rhs"]) < 1e-10
+    assert abs(cost - float(g["cost"])) < 1e-11 * float(g["cost"])
+
+
+@pytest.mark.parametrize("name,seed", [("c1", 0), ("c1", 5)])
+def test_schur_blocks_match_oracle(orc, name, seed):
+    sc = synth.make_ba_config(name, seed=seed)
+    ref, gpu = both(orc, sc)
+    rng = np.random.default_rng(seed)
+    dc = rng.uniform(0.1, 1.0, 6 * sc.Nc); dp = rng.uniform(0.1, 1.0, 3 * sc.Np)
+    s = ref.schur(dc=dc, dp=dp)
+    gpu.linearize(dc, dp)
+    S, rhs, cost = dense_from(gpu)
+    assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10
+    Vinv6, gp = gpu.landmark_blocks()
+    V = s["Vinv"]
+    ref6 = np.stack([V[:, 0, 0], V[:, 0, 1], V[:, 0, 2], V[:, 1, 1], V[:, 1, 2], V[:, 2, 2]], 1)
+    assert rel(Vinv6, ref6) < 1e-10 and rel(gp, s["gp"]) < 1e-10
+    br, bc = gpu.block_index()
+    assert np.all(br <= bc) and np.array_equal(br[:sc.Nc], np.arange(sc.Nc))
+    off = list(zip(br[sc.Nc:].tolist(), bc[sc.Nc:].tolist()))
+    assert off == sorted(off) and len(set(off)) == len(off)
+
+
+def test_medium_problem_with_many_work_items(orc):
+    sc = synth.make_ba_scene(50, 4000, 10, band=50, seed=11)     # config-2 shape at 1/5 scale
+    ref, gpu = both(orc, sc)
+    dc = np.full(6 * sc.Nc, 0.5); dp = np.full(3 * sc.Np, 0.5)
+    s = ref.schur(dc=dc, dp=dp)
+    gpu.linearize(dc, dp)
+    S, rhs, cost = dense_from(gpu)
+    assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10
+    assert abs(cost - ref.cost()) < 1e-11 * cost
+
+
+def test_unstaged_cameras_path(orc):
+    sc = synth.make_ba_scene(600, 3000, 4, band=16, seed=12)     # > 384 cameras: no LDS staging
+    ref, gpu = both(orc, sc)
+    dc = np.full(6 * sc.Nc, 0.5); dp = np.full(3 * sc.Np, 0.5)
+    s = ref.schur(dc=dc, dp=dp)
+    gpu.linearize(dc, dp)
+    S, rhs, _ = dense_from(gpu)
+    assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10
+
+
+def test_linearize_is_bitwise_reproducible():
+    sc = synth.make_ba_config("c1", seed=2)
+    gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    d = np.full(6 * sc.Nc, 0.1), np.full(3 * sc.Np, 0.1)
+    gpu.linearize(*d)
+    a = gpu.reduced_system()[2].copy()
+    gpu.linearize(*d)
+    assert np.array_equal(a, gpu.reduced_system()[2])
+
+
+def test_lm_step_matches_golden_and_oracle(orc, golden_dir):
+    g = np.load(golden_dir + "/ba_small.npz")
+    gpu = BAProblem.from_arrays(g["K"], g["t"], g["rpy"], g["pts"], g["cam"], g["pt"], g["uv"])
+    dcam, dpt, mcc = gpu.lm_step(float(g["radius"]))
+    assert rel(dcam, g["dcam"]) < 1e-6 and rel(dpt, g["dpt"]) < 1e-6
+    assert abs(mcc - float(g["mcc"])) < 1e-8 * abs(float(g["mcc"]))
+    gpu.set_fixed(True)
+    dcam, dpt, _ = gpu.lm_step(float(g["radius"]))
+    assert rel(dcam, g["dcam_fix"]) < 1e-10 and np.all(dpt == 0)
+    sc = synth.make_ba_config("c1", seed=4)
+    ref, gpu = both(orc, sc)
+    rc, dc0, dp0, mcc0, _, _ = ref.lm_step(1e4)
+    dc1, dp1, mcc1 = gpu.lm_step(1e4)
+    assert rc == 0
+    assert rel(dc1, dc0) < 1e-6 and rel(dp1, dp0) < 1e-6 and abs(mcc1 - mcc0) < 1e-8 * abs(mcc0)
+
+
+@pytest.mark.parametrize("fix_points", [True, False])
+def test_solve_matches_oracle(orc, fix_points):
+    sc = synth.make_ba_config("c1", seed=6)
+    pts = sc.pts_gt if fix_points else sc.pts0
+    ref, gpu = both(orc, sc, pts=pts, fix_points=fix_points, huber_a=100.0)
+    out0 = ref.solve()
+    out1 = gpu.solve()
+    assert out1["termination"] == out0["termination"]
+    assert out1["iterations"] == out0["iterations"]
+    assert out1["successful_steps"] == out0["successful_steps"]
+    assert abs(out1["initial_cost"] - out0["initial_cost"]) < 1e-10 * out0["initial_cost"]
+    assert abs(out1["final_cost"] - out0["final_cost"]) < 1e-7 * out0["final_cost"]
+    t, rpy = gpu.cameras()
+    assert rel(t, ref.t) < 1e-5 and rel(rpy, ref.rpy) < 1e-5          # north-star: 1e-5 relative
+    assert rel(gpu.points(), ref.pts) < 1e-5
+    assert out1["final_cost"] < 0.2 * out1["initial_cost"]
+
+
+def test_huber_first_edge_active(orc):
+    sc = synth.make_ba_config("c1", seed=8)
+    sc.uv = sc.uv.copy()
+    sc.uv[0] += 500.0                       # |r| > 100: Huber region of the first edge
+    ref, gpu = both(orc, sc, huber_a=100.0)
+    c0, r0, Jc0, Jp0 = ref.evaluate()
+    c1, r1, Jc1, Jp1 = gpu.evaluate()
+    assert abs(c1 - c0) < 1e-11 * c0 and rel(r1, r0) < 1e-11 and rel(Jc1, Jc0) < 1e-11
+    dc = np.full(6 * sc.Nc, 0.5); dp = np.full(3 * sc.Np, 0.5)
+    s = ref.schur(dc=dc, dp=dp)
+    gpu.linearize(dc, dp)
+    S, rhs, _ = dense_from(gpu)
+    assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert rel(d1, d0) < 1e-6 and abs(m1 - m0) < 1e-8 * abs(m0)
+
+
+def test_ragged_unobserved_points_and_cameras(orc):
+    sc = synth.make_ba_scene(8, 100, 3, band=6, seed=9)
+    keep = (sc.pt % 7 != 0) & (sc.cam != 5)          # some points and camera 5 lose all edges
+    sc.cam, sc.pt, sc.uv = sc.cam[keep], sc.pt[keep], sc.uv[keep]
+    ref, gpu = both(orc, sc, fix_points=True)
+    rc, d0, _, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert rc == 0 and rel(d1, d0) < 1e-9 and abs(m1 - m0) < 1e-9 * abs(m0)
+    assert np.all(d1[5] == 0)
+
+
+def test_sharded_partial_systems_sum_to_the_whole():
+    sc = synth.make_ba_config("c1", seed=10)
+    d = np.full(6 * sc.Nc, 0.3), np.full(3 * sc.Np, 0.3)
+    whole = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    whole.linearize(None, d[1])
+    br, bc, S, rhs, cost = whole.reduced_system()
+    acc_S, acc_rhs, acc_cost = 0, 0, 0
+    for r in range(3):
+        part = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=r, world=3)
+        part.linearize(None, d[1])
+        b2, c2, S2, rhs2, cost2 = part.reduced_system()
+        assert np.array_equal(b2, br) and np.array_equal(c2, bc)    # same block layout on every rank
+        acc_S = acc_S + S2; acc_rhs = acc_rhs + rhs2; acc_cost += cost2
+    assert rel(acc_S, S) < 1e-12 and rel(acc_rhs, rhs) < 1e-12 and abs(acc_cost - cost) < 1e-12 * cost
+
+
+def test_allreduce_hook_is_called_and_sums(orc):
+    """Two 'ranks' in one process: the hook adds the other shard's buffer, as an all-reduce would."""
+    import ctypes
+    sc = synth.make_ba_config("c1", seed=13)
+    ref = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    whole = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    dw, pw, mw = whole.lm_step(1e4)
+    assert rel(dw, d0) < 1e-6
+    calls = []
+    whole.set_allreduce(lambda p, n: calls.append(n))
+    whole.lm_step(1e4)
+    assert len(calls) >= 2 and calls[0] == whole.reduce_buffer()[1]
+
+
+def test_error_reporting():
+    sc = synth.make_ba_config("c1", seed=1)
+    cam = sc.cam.copy(); cam[3] = sc.Nc
+    with pytest.raises(VslamError) as e:
+        BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, cam, sc.pt, sc.uv)
+    assert e.value.code == -1 and "camera index" in str(e.value)
+    cam = np.concatenate([sc.cam, sc.cam[:1]]); pt = np.concatenate([sc.pt, sc.pt[:1]])
+    uv = np.concatenate([sc.uv, sc.uv[:1]])
+    with pytest.raises(VslamError) as e:
+        BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, cam, pt, uv)
+    assert "observed twice" in str(e.value)
+    p = BAProblem(2, 2, 1, sc.K)
+    with pytest.raises(VslamError) as e:
+        p.linearize()
+    assert e.value.code == -4
+
+
+def test_optimizer_mirror_runs_the_reference_call_order(orc):
+    """Tracking::solveCamera's sequence (tracking.cc:79-120) through the Optimizer mirror."""
+    from visual_slam_amd import optimizer as vo
+    sc, tracks, keys = synth.make_tracks_scene(6, 200, seed=4)
+    K = np.eye(3, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 170.5, 170.5, 191.5, 103.4
+    opt = vo.Optimizer()
+    for f in range(6):
+        q = vo.rpy_to_quat_f32(sc.rpy0[f].astype(np.float32))
+        opt.addPose(vo.Rigid3f(sc.t0[f], q))
+        opt.addKeys(keys[f])
+    opt.addPoints([vo.TrackedPoint(p) for p in sc.pts_gt])
+    prob = vo.Problem()
+    opt.addReprojectionEdges(prob, K, list(tracks), True)
+    # the same edge set and parameters through the oracle
+    cam, pt, uv = orc.build_edges(tracks, keys)
+    t = np.array([p[0] for p in opt.poses_]); rpy = np.array([p[1] for p in opt.poses_])
+    ref = orc.Problem(orc.K4(), t, rpy, np.array(opt.points_), cam, pt, uv, huber_a=100.0, fix_points=True)
+    out0 = ref.solve()
+    out1 = opt.solve()
+    assert out1["iterations"] == out0["iterations"]
+    assert abs(out1["final_cost"] - out0["final_cost"]) < 1e-7 * out0["final_cost"]
+    for f in range(6):
+        pose = opt.getPose(f)
+        assert np.abs(pose.translation - ref.t[f].astype(np.float32)).max() < 1e-5

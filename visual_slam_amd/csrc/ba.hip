@@ -1,0 +1,811 @@
+// Host side of the bundle-adjustment C ABI: index-structure construction, kernel sequencing,
+// the Levenberg-Marquardt loop.  Reference interfaces replaced are cited in include/vslam_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "ba_kernels.h"
+#include "dense_solve.h"
+
+using namespace vs;
+
+namespace {
+
+// Open-addressing map from a camera pair (a < b) to a block id; grows at 50 % load.
+struct PairMap {
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> vals;
+    uint64_t mask = 0;
+    size_t count = 0;
+    static constexpr uint64_t kEmpty = ~0ull;
+    void init(size_t cap_hint)
+    {
+        size_t cap = 1024;
+        while (cap < cap_hint) cap <<= 1;
+        keys.assign(cap, kEmpty);
+        vals.assign(cap, -1);
+        mask = cap - 1;
+        count = 0;
+    }
+    static uint64_t hash(uint64_t k)
+    {
+        k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+        return k;
+    }
+    size_t slot(uint64_t k) const
+    {
+        size_t s = hash(k) & mask;
+        while (keys[s] != kEmpty && keys[s] != k) s = (s + 1) & mask;
+        return s;
+    }
+    void grow()
+    {
+        std::vector<uint64_t> ok;
+        std::vector<int32_t> ov;
+        ok.swap(keys); ov.swap(vals);
+        init(ok.size() * 2);
+        for (size_t i = 0; i < ok.size(); i++)
+            if (ok[i] != kEmpty) { const size_t s = slot(ok[i]); keys[s] = ok[i]; vals[s] = ov[i]; count++; }
+    }
+    // true when the key was absent (it is inserted with value -1)
+    bool insert(uint64_t k)
+    {
+        if ((count + 1) * 2 > keys.size()) grow();
+        const size_t s = slot(k);
+        if (keys[s] != kEmpty) return false;
+        keys[s] = k; count++;
+        return true;
+    }
+    void set(uint64_t k, int32_t v) { vals[slot(k)] = v; }
+    int32_t get(uint64_t k) const
+    {
+        const size_t s = slot(k);
+        return keys[s] == kEmpty ? -1 : vals[s];
+    }
+};
+
+}  // namespace
+
+struct vs_ba {
+    int Nc = 0, Np = 0;
+    int64_t No_global = 0;   // edges handed to set_observations
+    int No = 0;              // edges this handle linearises (== No_global unless sharded)
+    Intr K{};
+    hipStream_t stream = nullptr;
+    bool fix_points = false;
+    double huber_a = 0.0;
+    bool have_cams = false, have_pts = false, have_obs = false, linearized = false;
+    bool have_scale = false;
+    int rank = 0, world = 1;
+    HuberObs hub{ -1, -1, -1, 0.0 };
+    int nb_off = 0, n_diag_items = 0, n_off_items = 0, n_lm_blocks = 0;
+    bool stage_cams = false;
+    int64_t red_len = 0;
+    vs_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+
+    std::vector<int32_t> h_brow, h_bcol;
+
+    DevBuf<real> t, rpy, pts, t2, rpy2, pts2;
+    DevBuf<CamData> cams;
+    DevBuf<int> pt_ptr, lcam, lpt, lobs, cam_ptr, cobs, brow, bcol, bent;
+    DevBuf<int> ditem_cam, ditem_begin, ditem_end, ditem_ptr;
+    DevBuf<int> oitem_block, oitem_begin, oitem_end, oitem_ptr;
+    DevBuf<unsigned char> cam_used, pt_used;
+    DevBuf<real> luv, Vinv6, gp, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
+    DevBuf<real> scale_c, scale_p, lam_c, lam_c_user, lam_p_user, dcam, dpt, mcc_partial,
+        cand_partial, scalars, dense, linv;
+    DevBuf<int> info;
+
+    real *S_diag() { return red.p; }
+    real *S_off() { return red.p + (int64_t)Nc * 36; }
+    real *rhs() { return S_off() + (int64_t)nb_off * 36; }
+    real *udiag() { return rhs() + 6 * (int64_t)Nc; }
+    real *gc() { return udiag() + 6 * (int64_t)Nc; }
+    real *cost() { return gc() + 6 * (int64_t)Nc; }
+};
+
+namespace {
+
+int launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s launch failed: %s", what, hipGetErrorString(e));
+        return VS_ERR_HIP;
+    }
+    return VS_OK;
+}
+
+int prep_cameras(vs_ba *h, const real *t, const real *rpy)
+{
+    hipLaunchKernelGGL(prep_cameras_kernel, dim3(div_up(h->Nc, 64)), dim3(64), 0, h->stream, h->Nc,
+                       t, rpy, h->cams.p);
+    return launch_check("prep_cameras");
+}
+
+size_t cam_lds_bytes(const vs_ba *h) { return h->stage_cams ? (size_t)h->Nc * sizeof(CamData) : 0; }
+
+// Builds every index structure from the caller's edge list (host side, once per edge set).
+int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const double *uv)
+{
+    const int Nc = h->Nc, Np = h->Np;
+    const int64_t Ng = h->No_global;
+    for (int64_t o = 0; o < Ng; o++) {
+        VS_CHECK(cam[o] >= 0 && cam[o] < Nc, VS_ERR_INVALID, "observation %lld: camera index %d out of range [0,%d)", (long long)o, cam[o], Nc);
+        VS_CHECK(pt[o] >= 0 && pt[o] < Np, VS_ERR_INVALID, "observation %lld: point index %d out of range [0,%d)", (long long)o, pt[o], Np);
+    }
+    // global landmark CSR
+    std::vector<int64_t> gptr((size_t)Np + 1, 0);
+    for (int64_t o = 0; o < Ng; o++) gptr[pt[o] + 1]++;
+    for (int j = 0; j < Np; j++) gptr[j + 1] += gptr[j];
+    std::vector<int64_t> gord((size_t)std::max<int64_t>(Ng, 1));
+    {
+        std::vector<int64_t> fill(gptr.begin(), gptr.end() - 1);
+        for (int64_t o = 0; o < Ng; o++) gord[fill[pt[o]]++] = o;
+    }
+    // shard: contiguous landmark range balanced by observation count
+    int pt_lo = 0, pt_hi = Np;
+    if (h->world > 1) {
+        auto bound = [&](int r) {
+            const int64_t target = Ng * r / h->world;
+            return (int)(std::lower_bound(gptr.begin(), gptr.end(), target) - gptr.begin());
+        };
+        pt_lo = std::min(bound(h->rank), Np);
+        pt_hi = h->rank == h->world - 1 ? Np : std::min(bound(h->rank + 1), Np);
+        if (pt_hi < pt_lo) pt_hi = pt_lo;
+    }
+    const int64_t lo_pos = gptr[pt_lo], hi_pos = gptr[pt_hi];
+    VS_CHECK(hi_pos - lo_pos < (int64_t)1 << 31, VS_ERR_UNSUPPORTED, "more than 2^31 observations on one GPU");
+    const int No = (int)(hi_pos - lo_pos);
+    h->No = No;
+
+    // landmark-major arrays (local), cameras ascending within a landmark
+    std::vector<int> pt_ptr((size_t)Np + 1, 0), lcam((size_t)std::max(No, 1)), lpt((size_t)std::max(No, 1)), lobs((size_t)std::max(No, 1));
+    std::vector<real> luv((size_t)std::max(No, 1) * 2);
+    std::vector<unsigned char> cam_used((size_t)Nc, 0), pt_used((size_t)Np, 0);
+    for (int64_t o = 0; o < Ng; o++) { cam_used[cam[o]] = 1; pt_used[pt[o]] = 1; }
+    h->hub = HuberObs{ -1, -1, -1, (real)h->huber_a };
+    std::vector<std::pair<int, int64_t>> tmp;
+    // global pattern of camera pairs + local entries
+    PairMap pmap;
+    pmap.init(1 << 16);
+    std::vector<uint64_t> uniq;
+    for (int j = 0; j < Np; j++) {
+        const int64_t b = gptr[j], e = gptr[j + 1];
+        tmp.clear();
+        for (int64_t k = b; k < e; k++) tmp.emplace_back(cam[gord[k]], gord[k]);
+        std::sort(tmp.begin(), tmp.end());
+        for (size_t a = 1; a < tmp.size(); a++)
+            VS_CHECK(tmp[a].first != tmp[a - 1].first, VS_ERR_INVALID, "point %d is observed twice by camera %d", j, tmp[a].first);
+        const bool local = j >= pt_lo && j < pt_hi;
+        if (local) {
+            pt_ptr[j] = (int)(b - lo_pos);
+            for (size_t a = 0; a < tmp.size(); a++) {
+                const int pos = (int)(b - lo_pos + a);
+                const int64_t o = tmp[a].second;
+                lcam[pos] = tmp[a].first; lpt[pos] = j; lobs[pos] = (int)o;
+                luv[2 * (size_t)pos] = uv[2 * o]; luv[2 * (size_t)pos + 1] = uv[2 * o + 1];
+                if (o == 0 && h->huber_a > 0.0) { h->hub.pos = pos; h->hub.cam = tmp[a].first; h->hub.pt = j; }
+            }
+        } else {
+            pt_ptr[j] = j < pt_lo ? 0 : No;
+        }
+        {
+            for (size_t a = 0; a < tmp.size(); a++)
+                for (size_t c = a + 1; c < tmp.size(); c++) {
+                    const uint64_t key = ((uint64_t)(uint32_t)tmp[a].first << 32) | (uint32_t)tmp[c].first;
+                    if (pmap.insert(key)) uniq.push_back(key);
+                }
+        }
+    }
+    pt_ptr[Np] = No;
+    for (int j = pt_hi; j < Np; j++) pt_ptr[j] = No;
+    VS_CHECK(Ng < ((int64_t)1 << 31), VS_ERR_UNSUPPORTED, "more than 2^31 observations");
+    std::sort(uniq.begin(), uniq.end());
+    const int nb_off = (int)uniq.size();
+    h->nb_off = nb_off;
+    h->h_brow.resize((size_t)nb_off); h->h_bcol.resize((size_t)nb_off);
+    for (int b = 0; b < nb_off; b++) {
+        pmap.set(uniq[b], b);
+        h->h_brow[b] = (int32_t)(uniq[b] >> 32); h->h_bcol[b] = (int32_t)(uniq[b] & 0xffffffffu);
+    }
+    // local entries per block (counting sort; landmarks ascending within a block)
+    std::vector<int> bptr((size_t)nb_off + 1, 0);
+    for (int j = pt_lo; j < pt_hi; j++) {
+        const int b = pt_ptr[j], e = (j + 1 < Np) ? pt_ptr[j + 1] : No;
+        for (int a = b; a < e; a++)
+            for (int c = a + 1; c < e; c++)
+                bptr[pmap.get(((uint64_t)(uint32_t)lcam[a] << 32) | (uint32_t)lcam[c]) + 1]++;
+    }
+    for (int b = 0; b < nb_off; b++) {
+        VS_CHECK((int64_t)bptr[b + 1] + bptr[b] < ((int64_t)1 << 31), VS_ERR_UNSUPPORTED, "more than 2^31 camera-pair entries on one GPU");
+        bptr[b + 1] += bptr[b];
+    }
+    const int n_ent = bptr[nb_off];
+    std::vector<int> bent((size_t)std::max(n_ent, 1));
+    {
+        std::vector<int> fill(bptr.begin(), bptr.end() - 1);
+        for (int j = pt_lo; j < pt_hi; j++) {
+            const int b = pt_ptr[j], e = (j + 1 < Np) ? pt_ptr[j + 1] : No;
+            for (int a = b; a < e; a++)
+                for (int c = a + 1; c < e; c++)
+                    bent[fill[pmap.get(((uint64_t)(uint32_t)lcam[a] << 32) | (uint32_t)lcam[c])]++] = j;
+        }
+    }
+    // camera-major view of the local observations
+    std::vector<int> cam_ptr((size_t)Nc + 1, 0), cobs((size_t)std::max(No, 1));
+    for (int p = 0; p < No; p++) cam_ptr[lcam[p] + 1]++;
+    for (int c = 0; c < Nc; c++) cam_ptr[c + 1] += cam_ptr[c];
+    {
+        std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+        for (int p = 0; p < No; p++) cobs[fill[lcam[p]]++] = p;
+    }
+    // work items: chunks sized so that the grid holds a few thousand waves
+    auto chunk_of = [](int64_t total) {
+        int64_t c = (total / 4096 + 63) / 64 * 64;
+        return (int)std::min<int64_t>(std::max<int64_t>(c, 64), 1024);
+    };
+    std::vector<int> di_cam, di_b, di_e, di_ptr((size_t)Nc + 1, 0);
+    {
+        const int ch = chunk_of(No);
+        for (int c = 0; c < Nc; c++) {
+            for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += ch) {
+                di_cam.push_back(c); di_b.push_back(b); di_e.push_back(std::min(b + ch, cam_ptr[c + 1]));
+            }
+            di_ptr[c + 1] = (int)di_cam.size();
+        }
+    }
+    std::vector<int> oi_blk, oi_b, oi_e, oi_ptr((size_t)nb_off + 1, 0);
+    {
+        const int ch = chunk_of(n_ent);
+        for (int k = 0; k < nb_off; k++) {
+            for (int b = bptr[k]; b < bptr[k + 1]; b += ch) {
+                oi_blk.push_back(k); oi_b.push_back(b); oi_e.push_back(std::min(b + ch, bptr[k + 1]));
+            }
+            oi_ptr[k + 1] = (int)oi_blk.size();
+        }
+    }
+    h->n_diag_items = (int)di_cam.size();
+    h->n_off_items = (int)oi_blk.size();
+    h->n_lm_blocks = div_up(Np, kLmThreads);
+    h->stage_cams = (size_t)Nc * sizeof(CamData) <= 48 * 1024;
+
+    hipStream_t s = h->stream;
+    VS_TRY(h->pt_ptr.upload(pt_ptr.data(), pt_ptr.size(), s));
+    VS_TRY(h->lcam.upload(lcam.data(), lcam.size(), s));
+    VS_TRY(h->lpt.upload(lpt.data(), lpt.size(), s));
+    VS_TRY(h->lobs.upload(lobs.data(), lobs.size(), s));
+    VS_TRY(h->luv.upload(luv.data(), luv.size(), s));
+    VS_TRY(h->cam_ptr.upload(cam_ptr.data(), cam_ptr.size(), s));
+    VS_TRY(h->cobs.upload(cobs.data(), cobs.size(), s));
+    VS_TRY(h->cam_used.upload(cam_used.data(), cam_used.size(), s));
+    VS_TRY(h->pt_used.upload(pt_used.data(), pt_used.size(), s));
+    std::vector<int> one(1, 0);
+    VS_TRY(h->brow.upload(nb_off ? h->h_brow.data() : one.data(), std::max(nb_off, 1), s));
+    VS_TRY(h->bcol.upload(nb_off ? h->h_bcol.data() : one.data(), std::max(nb_off, 1), s));
+    VS_TRY(h->bent.upload(bent.data(), bent.size(), s));
+    auto up = [&](DevBuf<int> &d, std::vector<int> &v) { if (v.empty()) v.push_back(0); return d.upload(v.data(), v.size(), s); };
+    VS_TRY(up(h->ditem_cam, di_cam)); VS_TRY(up(h->ditem_begin, di_b)); VS_TRY(up(h->ditem_end, di_e));
+    VS_TRY(up(h->ditem_ptr, di_ptr));
+    VS_TRY(up(h->oitem_block, oi_blk)); VS_TRY(up(h->oitem_begin, oi_b)); VS_TRY(up(h->oitem_end, oi_e));
+    VS_TRY(up(h->oitem_ptr, oi_ptr));
+    VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
+    VS_TRY(h->off_partial.alloc((size_t)std::max(h->n_off_items, 1) * kOffVals));
+    VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
+    VS_TRY(h->mcc_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
+    h->red_len = (int64_t)Nc * 36 + (int64_t)nb_off * 36 + 18 * (int64_t)Nc + 1;
+    VS_TRY(h->red.alloc((size_t)h->red_len));
+    VS_HIP(hipMemsetAsync(h->red.p, 0, (size_t)h->red_len * sizeof(real), s));
+    const real one_r = 1.0;
+    VS_HIP(hipMemcpyAsync(h->hub_w.p, &one_r, sizeof(real), hipMemcpyHostToDevice, s));
+    VS_HIP(hipStreamSynchronize(s));
+    h->have_obs = true;
+    h->linearized = false;
+    h->have_scale = false;
+    return VS_OK;
+}
+
+// Linearise at parameters (t,rpy,pts on device) and form the undamped-camera reduced system in
+// h->red.  Point damping is applied inside (it is local to a landmark); camera damping later.
+int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDamping pd)
+{
+    VS_TRY(prep_cameras(h, t, rpy));
+    const size_t lds = cam_lds_bytes(h);
+    if (h->stage_cams)
+        hipLaunchKernelGGL(landmark_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, h->stream,
+                           h->Np, h->Nc, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
+                           h->Vinv6.p, h->gp.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+    else
+        hipLaunchKernelGGL(landmark_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, h->stream,
+                           h->Np, h->Nc, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
+                           h->Vinv6.p, h->gp.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+    VS_TRY(launch_check("landmark_kernel"));
+    if (h->n_diag_items > 0) {
+        hipLaunchKernelGGL(diag_kernel, dim3(div_up(h->n_diag_items, kItemWaves)), dim3(kItemWaves * kWave), 0,
+                           h->stream, h->n_diag_items, h->ditem_cam.p, h->ditem_begin.p, h->ditem_end.p, h->K,
+                           h->cams.p, pts, h->cobs.p, h->lpt.p, h->luv.p, h->hub, h->hub_w.p,
+                           (int)h->fix_points, h->Vinv6.p, h->gp.p, h->diag_partial.p);
+        VS_TRY(launch_check("diag_kernel"));
+    }
+    if (!h->fix_points && h->n_off_items > 0) {
+        hipLaunchKernelGGL(offdiag_kernel, dim3(div_up(h->n_off_items, kItemWaves)), dim3(kItemWaves * kWave), 0,
+                           h->stream, h->n_off_items, h->oitem_block.p, h->oitem_begin.p, h->oitem_end.p,
+                           h->brow.p, h->bcol.p, h->K, h->cams.p, pts, h->bent.p, h->hub, h->hub_w.p,
+                           h->Vinv6.p, h->off_partial.p);
+        VS_TRY(launch_check("offdiag_kernel"));
+    }
+    const int nb_fin = h->fix_points ? 0 : h->nb_off;
+    if (h->fix_points && h->nb_off > 0)
+        VS_HIP(hipMemsetAsync(h->S_off(), 0, (size_t)h->nb_off * 36 * sizeof(real), h->stream));
+    const int64_t n_fin = (int64_t)h->Nc * kDiagVals + (int64_t)nb_fin * kOffVals + 1;
+    hipLaunchKernelGGL(finalize_kernel, dim3(div_up(n_fin, 256)), dim3(256), 0, h->stream, h->Nc, h->nb_off, nb_fin,
+                       h->ditem_ptr.p, h->diag_partial.p, h->oitem_ptr.p, h->off_partial.p, h->n_lm_blocks,
+                       h->cost_partial.p, h->red.p);
+    VS_TRY(launch_check("finalize_kernel"));
+    h->linearized = true;
+    return VS_OK;
+}
+
+int ensure_state(vs_ba *h)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(h->have_cams && h->have_pts && h->have_obs, VS_ERR_STATE,
+             "cameras, points and observations must be set first");
+    return VS_OK;
+}
+
+int cross_gpu_sum(vs_ba *h, real *buf, int64_t n)
+{
+    if (!h->allreduce) return VS_OK;
+    VS_HIP(hipStreamSynchronize(h->stream));
+    const int rc = h->allreduce(h->allreduce_user, buf, n);
+    VS_CHECK(rc == 0, VS_ERR_HIP, "all-reduce callback failed with code %d", rc);
+    return VS_OK;
+}
+
+struct StepScalars { real mcc, xnorm2, snorm2, cost_new; };
+
+// One LM step at the handle's current parameters.  Leaves dcam/dpt and the candidate
+// parameters (t2,rpy2,pts2) on the device; fills sc (host).  *numeric_fail set when the reduced
+// system is not positive definite.
+int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScalars *sc,
+                   bool *numeric_fail, bool want_candidate_cost)
+{
+    hipStream_t s = h->stream;
+    const int Nc = h->Nc, Np = h->Np;
+    if (!h->have_scale) {
+        // Jacobi scaling from the Jacobian at the first iterate
+        PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
+        const bool fp = h->fix_points;
+        h->fix_points = true;   // only diag(U), diag(V) are needed: skip the Schur terms
+        int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none);
+        h->fix_points = fp;
+        VS_TRY(rc);
+        VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+        hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(6 * Nc, 256)), dim3(256), 0, s, 6 * Nc, h->udiag(), h->scale_c.p);
+        hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(3 * (int64_t)Np, 256)), dim3(256), 0, s, 3 * Np, h->Vdiag.p, h->scale_p.p);
+        VS_TRY(launch_check("jacobi_scale_kernel"));
+        h->have_scale = true;
+    }
+    PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)min_d, (real)max_d };
+    VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
+    VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+    hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * Nc, 256)), dim3(256), 0, s, Nc, h->udiag(),
+                       h->scale_c.p, (const real *)nullptr, (real)radius, (real)min_d, (real)max_d, h->lam_c.p, h->S_diag());
+    VS_TRY(launch_check("camera_damping_kernel"));
+    VS_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), s));
+    if (h->fix_points || h->nb_off == 0) {
+        hipLaunchKernelGGL(solve6_kernel, dim3(div_up(Nc, 64)), dim3(64), 0, s, Nc, h->S_diag(), h->rhs(), h->dcam.p, h->info.p);
+        VS_TRY(launch_check("solve6_kernel"));
+    } else {
+        const int n = 6 * Nc;
+        VS_CHECK((int64_t)n * n * sizeof(real) <= (int64_t)8 << 30, VS_ERR_UNSUPPORTED,
+                 "dense reduced system of %d cameras exceeds this build's solver limit", Nc);
+        if (h->dense.n < (size_t)n * n) VS_TRY(h->dense.alloc((size_t)n * n));
+        VS_HIP(hipMemsetAsync(h->dense.p, 0, (size_t)n * n * sizeof(real), s));
+        const int64_t ne = (int64_t)Nc * 36 + (int64_t)h->nb_off * 36;
+        hipLaunchKernelGGL(assemble_lower_kernel, dim3(div_up(ne, 256)), dim3(256), 0, s, Nc, h->nb_off,
+                           h->brow.p, h->bcol.p, h->S_diag(), h->S_off(), h->dense.p, n);
+        VS_TRY(launch_check("assemble_lower_kernel"));
+        VS_HIP(hipMemcpyAsync(h->dcam.p, h->rhs(), (size_t)n * sizeof(real), hipMemcpyDeviceToDevice, s));
+        VS_TRY(dense_cholesky_solve(h->dense.p, h->dcam.p, n, h->info.p, h->linv.p, s));
+    }
+    const size_t lds = cam_lds_bytes(h);
+    if (h->stage_cams)
+        hipLaunchKernelGGL(backsub_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
+                           h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p,
+                           (int)h->fix_points, h->Vinv6.p, h->gp.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
+    else
+        hipLaunchKernelGGL(backsub_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, Np, Nc, h->K,
+                           h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p,
+                           (int)h->fix_points, h->Vinv6.p, h->gp.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
+    VS_TRY(launch_check("backsub_kernel"));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->mcc_partial.p, h->scalars.p);
+    const int64_t npar = 6 * (int64_t)Nc + 3 * (int64_t)Np;
+    const int ncb = div_up(npar, 256);
+    if (h->cand_partial.n < (size_t)ncb * 2) VS_TRY(h->cand_partial.alloc((size_t)ncb * 2 + 2));
+    hipLaunchKernelGGL(candidate_kernel, dim3(ncb), dim3(256), 0, s, Nc, Np, (int)h->fix_points, h->t.p, h->rpy.p,
+                       h->pts.p, h->cam_used.p, h->pt_used.p, (int)(h->rank == 0), h->dcam.p, h->dpt.p,
+                       h->t2.p, h->rpy2.p, h->pts2.p, h->cand_partial.p);
+    VS_TRY(launch_check("candidate_kernel"));
+    // |x|^2 and |d|^2: strided sums of the interleaved partials
+    std::vector<real> hp;
+    if (want_candidate_cost) {
+        VS_TRY(prep_cameras(h, h->t2.p, h->rpy2.p));
+        if (h->stage_cams)
+            hipLaunchKernelGGL(cost_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
+                               h->cams.p, h->pts2.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+        else
+            hipLaunchKernelGGL(cost_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, Np, Nc, h->K,
+                               h->cams.p, h->pts2.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+        VS_TRY(launch_check("cost_kernel"));
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->cost_partial.p, h->scalars.p + 3);
+    }
+    hp.resize((size_t)ncb * 2);
+    VS_HIP(hipMemcpyAsync(hp.data(), h->cand_partial.p, hp.size() * sizeof(real), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    real xn = 0, dn = 0;
+    for (int i = 0; i < ncb; i++) { xn += hp[2 * (size_t)i]; dn += hp[2 * (size_t)i + 1]; }
+    real host4[4] = { 0, xn, dn, 0 };
+    VS_HIP(hipMemcpyAsync(h->scalars.p + 1, host4 + 1, 2 * sizeof(real), hipMemcpyHostToDevice, s));
+    VS_TRY(cross_gpu_sum(h, h->scalars.p, 4));
+    VS_HIP(hipMemcpyAsync(host4, h->scalars.p, 4 * sizeof(real), hipMemcpyDeviceToHost, s));
+    int info = 0;
+    VS_HIP(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    sc->mcc = host4[0]; sc->xnorm2 = host4[1]; sc->snorm2 = host4[2]; sc->cost_new = host4[3];
+    *numeric_fail = info != 0;
+    return VS_OK;
+}
+
+int gradient_max(vs_ba *h, real *out)
+{
+    hipLaunchKernelGGL(gradient_max_kernel, dim3(1), dim3(256), 0, h->stream, (int64_t)6 * h->Nc, h->gc(),
+                       h->fix_points ? (int64_t)0 : 3 * (int64_t)h->Np, h->gp.p, h->scalars.p + 4);
+    VS_TRY(launch_check("gradient_max_kernel"));
+    VS_HIP(hipMemcpyAsync(out, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, h->stream));
+    VS_HIP(hipStreamSynchronize(h->stream));
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vs_lm_default_options(vs_lm_options *o)
+{
+    if (!o) return;
+    o->max_num_iterations = 100;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->max_consecutive_invalid_steps = 5;
+}
+
+int vs_ba_create(vs_ba_handle *out, int32_t Nc, int32_t Np, int64_t No, double fx, double fy,
+                 double cx, double cy)
+{
+    VS_CHECK(out != nullptr, VS_ERR_INVALID, "null handle pointer");
+    *out = nullptr;
+    VS_CHECK(Nc > 0 && Np > 0 && No >= 0, VS_ERR_INVALID, "sizes must be positive (Nc=%d Np=%d No=%lld)", Nc, Np, (long long)No);
+    int ndev = 0;
+    VS_HIP(hipGetDeviceCount(&ndev));
+    VS_CHECK(ndev > 0, VS_ERR_HIP, "no HIP device available");
+    vs_ba *h = new (std::nothrow) vs_ba();
+    VS_CHECK(h != nullptr, VS_ERR_NOMEM, "out of host memory");
+    h->Nc = Nc; h->Np = Np; h->No_global = No;
+    h->K = Intr{ fx, fy, cx, cy };
+    int rc = VS_OK;
+    auto A = [&](int r) { if (rc == VS_OK) rc = r; };
+    A(h->t.alloc(3 * (size_t)Nc)); A(h->rpy.alloc(3 * (size_t)Nc)); A(h->pts.alloc(3 * (size_t)Np));
+    A(h->t2.alloc(3 * (size_t)Nc)); A(h->rpy2.alloc(3 * (size_t)Nc)); A(h->pts2.alloc(3 * (size_t)Np));
+    A(h->cams.alloc((size_t)Nc));
+    A(h->Vinv6.alloc(6 * (size_t)Np)); A(h->gp.alloc(3 * (size_t)Np)); A(h->Vdiag.alloc(3 * (size_t)Np));
+    A(h->hub_w.alloc(1)); A(h->scale_c.alloc(6 * (size_t)Nc)); A(h->scale_p.alloc(3 * (size_t)Np));
+    A(h->lam_c.alloc(6 * (size_t)Nc)); A(h->dcam.alloc(6 * (size_t)Nc)); A(h->dpt.alloc(3 * (size_t)Np));
+    A(h->scalars.alloc(8)); A(h->info.alloc(1)); A(h->linv.alloc(kNB * kNB));
+    if (rc != VS_OK) { delete h; return rc; }
+    *out = h;
+    return VS_OK;
+}
+
+int vs_ba_destroy(vs_ba_handle h)
+{
+    if (h) { (void)hipStreamSynchronize(h->stream); delete h; }
+    return VS_OK;
+}
+
+int vs_ba_set_stream(vs_ba_handle h, void *stream)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    h->stream = (hipStream_t)stream;
+    return VS_OK;
+}
+
+int vs_ba_set_cameras(vs_ba_handle h, const double *t, const double *rpy)
+{
+    VS_CHECK(h && t && rpy, VS_ERR_INVALID, "null argument");
+    VS_HIP(hipMemcpyAsync(h->t.p, t, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
+    VS_HIP(hipMemcpyAsync(h->rpy.p, rpy, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
+    VS_HIP(hipStreamSynchronize(h->stream));
+    h->have_cams = true; h->linearized = false; h->have_scale = false;
+    return VS_OK;
+}
+
+int vs_ba_set_points(vs_ba_handle h, const double *xyz)
+{
+    VS_CHECK(h && xyz, VS_ERR_INVALID, "null argument");
+    VS_HIP(hipMemcpyAsync(h->pts.p, xyz, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+    VS_HIP(hipStreamSynchronize(h->stream));
+    h->have_pts = true; h->linearized = false; h->have_scale = false;
+    return VS_OK;
+}
+
+int vs_ba_set_observations_sharded(vs_ba_handle h, const int32_t *cam, const int32_t *pt,
+                                   const double *uv, int32_t rank, int32_t world)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(h->No_global == 0 || (cam && pt && uv), VS_ERR_INVALID, "null observation arrays");
+    VS_CHECK(world >= 1 && rank >= 0 && rank < world, VS_ERR_INVALID, "bad shard %d of %d", rank, world);
+    h->rank = rank; h->world = world;
+    return build_structure(h, cam, pt, uv);
+}
+
+int vs_ba_set_observations(vs_ba_handle h, const int32_t *cam, const int32_t *pt, const double *uv)
+{
+    return vs_ba_set_observations_sharded(h, cam, pt, uv, 0, 1);
+}
+
+int vs_ba_set_fixed(vs_ba_handle h, int32_t fix_points)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    h->fix_points = fix_points != 0;
+    h->linearized = false; h->have_scale = false;
+    return VS_OK;
+}
+
+int vs_ba_set_huber_first(vs_ba_handle h, double a)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(!h->have_obs, VS_ERR_STATE, "set the loss before the observations");
+    h->huber_a = a > 0.0 ? a : 0.0;
+    return VS_OK;
+}
+
+int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double *Jp)
+{
+    VS_TRY(ensure_state(h));
+    hipStream_t s = h->stream;
+    VS_TRY(prep_cameras(h, h->t.p, h->rpy.p));
+    const int64_t Ng = h->No_global;
+    DevBuf<real> dres, dJc, dJp;
+    if (res) { VS_TRY(dres.alloc(2 * (size_t)Ng)); VS_HIP(hipMemsetAsync(dres.p, 0, 2 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
+    if (Jc) { VS_TRY(dJc.alloc(12 * (size_t)Ng)); VS_HIP(hipMemsetAsync(dJc.p, 0, 12 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
+    if (Jp) { VS_TRY(dJp.alloc(6 * (size_t)Ng)); VS_HIP(hipMemsetAsync(dJp.p, 0, 6 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
+    if ((res || Jc || Jp) && h->No > 0) {
+        hipLaunchKernelGGL(obs_jacobian_kernel, dim3(div_up(h->No, 256)), dim3(256), 0, s, h->No, h->K, h->cams.p,
+                           h->pts.p, h->lcam.p, h->lpt.p, h->luv.p, h->lobs.p, h->hub,
+                           res ? dres.p : nullptr, Jc ? dJc.p : nullptr, Jp ? dJp.p : nullptr);
+        VS_TRY(launch_check("obs_jacobian_kernel"));
+    }
+    if (cost) {
+        const size_t lds = cam_lds_bytes(h);
+        if (h->stage_cams)
+            hipLaunchKernelGGL(cost_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, h->Np, h->Nc, h->K,
+                               h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+        else
+            hipLaunchKernelGGL(cost_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, h->Np, h->Nc, h->K,
+                               h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+        VS_TRY(launch_check("cost_kernel"));
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->cost_partial.p, h->scalars.p + 5);
+        VS_HIP(hipMemcpyAsync(cost, h->scalars.p + 5, sizeof(real), hipMemcpyDefault, s));
+    }
+    if (res) VS_HIP(hipMemcpyAsync(res, dres.p, 2 * (size_t)Ng * sizeof(real), hipMemcpyDefault, s));
+    if (Jc) VS_HIP(hipMemcpyAsync(Jc, dJc.p, 12 * (size_t)Ng * sizeof(real), hipMemcpyDefault, s));
+    if (Jp) VS_HIP(hipMemcpyAsync(Jp, dJp.p, 6 * (size_t)Ng * sizeof(real), hipMemcpyDefault, s));
+    VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+int vs_ba_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p)
+{
+    VS_TRY(ensure_state(h));
+    hipStream_t s = h->stream;
+    PointDamping pd{ nullptr, nullptr, 1.0, 0.0, 0.0 };
+    if (damp_p) {
+        VS_TRY(h->lam_p_user.upload(damp_p, 3 * (size_t)h->Np, s));
+        pd.lam_p = h->lam_p_user.p;
+    }
+    if (damp_c) VS_TRY(h->lam_c_user.upload(damp_c, 6 * (size_t)h->Nc, s));
+    VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
+    if (damp_c) {
+        hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * h->Nc, 256)), dim3(256), 0, s, h->Nc, h->udiag(),
+                           (const real *)nullptr, h->lam_c_user.p, real(1), real(0), real(0), (real *)nullptr, h->S_diag());
+        VS_TRY(launch_check("camera_damping_kernel"));
+    }
+    return VS_OK;
+}
+
+int vs_ba_block_count(vs_ba_handle h, int64_t *n_blocks)
+{
+    VS_CHECK(h && n_blocks, VS_ERR_INVALID, "null argument");
+    VS_CHECK(h->have_obs, VS_ERR_STATE, "observations not set");
+    *n_blocks = (int64_t)h->Nc + h->nb_off;
+    return VS_OK;
+}
+
+int vs_ba_block_index(vs_ba_handle h, int32_t *block_row, int32_t *block_col)
+{
+    VS_CHECK(h && block_row && block_col, VS_ERR_INVALID, "null argument");
+    VS_CHECK(h->have_obs, VS_ERR_STATE, "observations not set");
+    for (int c = 0; c < h->Nc; c++) { block_row[c] = c; block_col[c] = c; }
+    for (int b = 0; b < h->nb_off; b++) { block_row[h->Nc + b] = h->h_brow[b]; block_col[h->Nc + b] = h->h_bcol[b]; }
+    return VS_OK;
+}
+
+int vs_ba_get_reduced_system(vs_ba_handle h, double *S_blocks, double *rhs, double *cost)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(h->linearized, VS_ERR_STATE, "call vs_ba_linearize first");
+    hipStream_t s = h->stream;
+    if (S_blocks) VS_HIP(hipMemcpyAsync(S_blocks, h->red.p, ((size_t)h->Nc + h->nb_off) * 36 * sizeof(real), hipMemcpyDefault, s));
+    if (rhs) VS_HIP(hipMemcpyAsync(rhs, h->rhs(), 6 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, s));
+    if (cost) VS_HIP(hipMemcpyAsync(cost, h->cost(), sizeof(real), hipMemcpyDefault, s));
+    VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+int vs_ba_get_landmark_blocks(vs_ba_handle h, double *Vinv6, double *gp)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(h->linearized, VS_ERR_STATE, "call vs_ba_linearize first");
+    hipStream_t s = h->stream;
+    if (Vinv6) VS_HIP(hipMemcpyAsync(Vinv6, h->Vinv6.p, 6 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, s));
+    if (gp) VS_HIP(hipMemcpyAsync(gp, h->gp.p, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, s));
+    VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+int vs_ba_reduce_buffer(vs_ba_handle h, void **device_ptr, int64_t *n_doubles)
+{
+    VS_CHECK(h && device_ptr && n_doubles, VS_ERR_INVALID, "null argument");
+    VS_CHECK(h->have_obs, VS_ERR_STATE, "observations not set");
+    *device_ptr = h->red.p;
+    *n_doubles = h->red_len;
+    return VS_OK;
+}
+
+int vs_ba_set_allreduce(vs_ba_handle h, vs_allreduce_fn fn, void *user)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    h->allreduce = fn; h->allreduce_user = user;
+    return VS_OK;
+}
+
+int vs_ba_lm_step(vs_ba_handle h, double radius, double *dcam, double *dpt, double *mcc)
+{
+    VS_TRY(ensure_state(h));
+    VS_CHECK(radius > 0.0, VS_ERR_INVALID, "radius must be positive");
+    vs_lm_options o;
+    vs_lm_default_options(&o);
+    StepScalars sc{};
+    bool fail = false;
+    VS_TRY(lm_step_device(h, radius, o.min_lm_diagonal, o.max_lm_diagonal, &sc, &fail, false));
+    VS_CHECK(!fail, VS_ERR_NUMERIC, "reduced camera system is not positive definite");
+    hipStream_t s = h->stream;
+    if (dcam) VS_HIP(hipMemcpyAsync(dcam, h->dcam.p, 6 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, s));
+    if (dpt) VS_HIP(hipMemcpyAsync(dpt, h->dpt.p, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, s));
+    VS_HIP(hipStreamSynchronize(s));
+    if (mcc) *mcc = sc.mcc;
+    return VS_OK;
+}
+
+int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summary)
+{
+    VS_TRY(ensure_state(h));
+    vs_lm_options o;
+    if (opts) o = *opts; else vs_lm_default_options(&o);
+    hipStream_t s = h->stream;
+    double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+    int it = 0, term = 1, nsucc = 0, invalid = 0;
+    double cost = 0.0, cost0 = 0.0;
+    h->have_scale = false;
+    // initial cost and gradient (unscaled, undamped)
+    {
+        PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
+        const bool fp = h->fix_points;
+        h->fix_points = true;
+        int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none);
+        h->fix_points = fp;
+        VS_TRY(rc);
+        VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+        VS_HIP(hipMemcpyAsync(&cost, h->cost(), sizeof(real), hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        cost0 = cost;
+    }
+    if (h->No_global == 0) term = 0;
+    else {
+        real gmax = 0;
+        VS_TRY(gradient_max(h, &gmax));
+        if (gmax <= o.gradient_tolerance) term = 0;
+        else
+            while (true) {
+                if (it >= o.max_num_iterations) { term = 1; break; }
+                if (radius < o.min_trust_region_radius) { term = 0; break; }
+                it++;
+                StepScalars sc{};
+                bool fail = false;
+                VS_TRY(lm_step_device(h, radius, o.min_lm_diagonal, o.max_lm_diagonal, &sc, &fail, true));
+                if (fail || !(sc.mcc > 0.0)) {
+                    if (++invalid > o.max_consecutive_invalid_steps) { term = 2; break; }
+                    radius *= 0.5;
+                    continue;
+                }
+                invalid = 0;
+                const double xn = std::sqrt(sc.xnorm2), sn = std::sqrt(sc.snorm2);
+                if (sn <= o.parameter_tolerance * (xn + o.parameter_tolerance)) { term = 0; break; }
+                const double change = cost - sc.cost_new;
+                if (std::fabs(change) <= o.function_tolerance * cost) { term = 0; break; }
+                const double rho = change / sc.mcc;
+                if (rho > o.min_relative_decrease) {
+                    std::swap(h->t.p, h->t2.p); std::swap(h->rpy.p, h->rpy2.p);
+                    if (!h->fix_points) std::swap(h->pts.p, h->pts2.p);
+                    cost = sc.cost_new; nsucc++;
+                    double f = 1.0 - std::pow(2.0 * rho - 1.0, 3.0);
+                    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+                    radius = std::min(radius / f, o.max_trust_region_radius);
+                    decrease_factor = 2.0;
+                    // gradient at the accepted point
+                    PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
+                    const bool fp = h->fix_points;
+                    h->fix_points = true;
+                    int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none);
+                    h->fix_points = fp;
+                    VS_TRY(rc);
+                    VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+                    VS_TRY(gradient_max(h, &gmax));
+                    if (gmax <= o.gradient_tolerance) { term = 0; break; }
+                } else {
+                    radius /= decrease_factor;
+                    decrease_factor *= 2.0;
+                }
+            }
+    }
+    h->linearized = false;
+    if (summary) {
+        summary->iterations = it; summary->successful_steps = nsucc; summary->termination = term;
+        summary->initial_cost = cost0; summary->final_cost = cost; summary->final_radius = radius;
+    }
+    return VS_OK;
+}
+
+int vs_ba_get_cameras(vs_ba_handle h, double *t, double *rpy)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(h->have_cams, VS_ERR_STATE, "cameras not set");
+    if (t) VS_HIP(hipMemcpyAsync(t, h->t.p, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
+    if (rpy) VS_HIP(hipMemcpyAsync(rpy, h->rpy.p, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
+    VS_HIP(hipStreamSynchronize(h->stream));
+    return VS_OK;
+}
+
+int vs_ba_get_points(vs_ba_handle h, double *xyz)
+{
+    VS_CHECK(h && xyz, VS_ERR_INVALID, "null argument");
+    VS_CHECK(h->have_pts, VS_ERR_STATE, "points not set");
+    VS_HIP(hipMemcpyAsync(xyz, h->pts.p, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+    VS_HIP(hipStreamSynchronize(h->stream));
+    return VS_OK;
+}
+
+}  // extern "C"

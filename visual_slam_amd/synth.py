@@ -1,0 +1,163 @@
+"""Seeded synthetic inputs of the shapes the benchmarks and parity tests use.
+
+Bundle-adjustment scenes follow the reference's camera model (camera looks along +Y, pose =
+translation + roll/pitch/yaw with R = Rz*Ry*Rx, Pc = R*Pw + t; /root/reference paths:
+src/core/reprojection_error.h:32-48) and its intrinsics (config/config.yaml:12-15, stored as float).
+Keypoints are rounded to integer pixels as the reference's cv::Point keys are
+(src/core/optimizer.cc:30-36).  Descriptors are L2-normalised 256-d fp32 rows like SuperPoint's
+(src/core/superpoint_frontend.cc:97-107).
+"""
+import numpy as np
+
+FX, FY, CX, CY = (float(np.float32(v)) for v in (170.5, 170.5, 191.5, 103.4))
+DESC_DIM = 256
+
+
+def rpy_to_R(rpy):
+    """R = Rz(yaw) Ry(pitch) Rx(roll) for an (..., 3) array of angles."""
+    rpy = np.asarray(rpy, dtype=np.float64)
+    sr, cr = np.sin(rpy[..., 0]), np.cos(rpy[..., 0])
+    sp, cp = np.sin(rpy[..., 1]), np.cos(rpy[..., 1])
+    sy, cy = np.sin(rpy[..., 2]), np.cos(rpy[..., 2])
+    R = np.empty(rpy.shape[:-1] + (3, 3))
+    R[..., 0, 0] = cy * cp; R[..., 0, 1] = cy * sp * sr - sy * cr; R[..., 0, 2] = cy * sp * cr + sy * sr
+    R[..., 1, 0] = sy * cp; R[..., 1, 1] = sy * sp * sr + cy * cr; R[..., 1, 2] = sy * sp * cr - cy * sr
+    R[..., 2, 0] = -sp; R[..., 2, 1] = cp * sr; R[..., 2, 2] = cp * cr
+    return R
+
+
+def project(pts, t, rpy, K=(FX, FY, CX, CY)):
+    """Pixel coordinates of points (N,3) seen from poses t (N,3), rpy (N,3); also returns depth."""
+    R = rpy_to_R(rpy)
+    pc = np.einsum("nij,nj->ni", R, pts) + t
+    u = K[0] * pc[:, 0] / pc[:, 1] + K[2]
+    v = -K[1] * pc[:, 2] / pc[:, 1] + K[3]
+    return np.stack([u, v], axis=1), pc[:, 1]
+
+
+class BAScene:
+    """cam/pt/uv observation lists plus ground-truth and perturbed initial parameters."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @property
+    def Nc(self):
+        return len(self.t0)
+
+    @property
+    def Np(self):
+        return len(self.pts0)
+
+    @property
+    def No(self):
+        return len(self.cam)
+
+
+def make_ba_scene(Nc, Np, k_mean, band=None, seed=0, k_jitter=2, cam_step=0.05, noise_px=0.5,
+                  pose_noise=(0.01, np.deg2rad(0.5)), pt_noise=0.01, chunk=200_000):
+    """Cameras on a sideways trajectory looking along +Y; each landmark is observed by about
+    `k_mean` distinct cameras drawn from a co-visibility band of `band` consecutive cameras.
+    Observations are emitted landmark-major (landmark ascending, camera ascending within one)."""
+    rng = np.random.default_rng(0xBA5EED + seed)
+    band = Nc if band is None else min(band, Nc)
+    k_lo = max(2, k_mean - k_jitter)
+    k_hi = min(band, k_mean + k_jitter)
+    # ground-truth cameras
+    cw = np.zeros((Nc, 3))
+    cw[:, 0] = np.arange(Nc) * cam_step
+    cw[:, 1] = rng.normal(0, 0.02, Nc)
+    cw[:, 2] = rng.normal(0, 0.02, Nc)
+    rpy_gt = rng.normal(0, np.deg2rad(2.0), (Nc, 3))
+    R = rpy_to_R(rpy_gt)
+    t_gt = -np.einsum("nij,nj->ni", R, cw)
+    # landmarks: in front of the band centre
+    first = rng.integers(0, Nc - band + 1, Np)
+    centre_x = (first + 0.5 * (band - 1)) * cam_step
+    depth = rng.uniform(1.0, 20.0, Np)
+    half_w = np.maximum(0.8 * depth * (CX / FX) - 0.5 * band * cam_step, 0.1 * depth)
+    pts_gt = np.empty((Np, 3))
+    pts_gt[:, 0] = centre_x + rng.uniform(-1, 1, Np) * half_w
+    pts_gt[:, 1] = depth
+    pts_gt[:, 2] = rng.uniform(-1, 1, Np) * 0.8 * depth * (CY / FY)
+    # pick k distinct cameras per landmark from its band
+    kk = rng.integers(k_lo, k_hi + 1, Np)
+    cams, pts_idx = [], []
+    for s in range(0, Np, chunk):
+        e = min(Np, s + chunk)
+        keys = rng.random((e - s, band))
+        order = np.argsort(keys, axis=1)[:, :k_hi]           # random distinct offsets
+        sel = np.arange(k_hi)[None, :] < kk[s:e, None]
+        off = np.where(sel, order, band)                       # pad with sentinel
+        off.sort(axis=1)                                       # camera ascending, sentinel last
+        rows = np.repeat(np.arange(s, e), k_hi).reshape(e - s, k_hi)
+        m = off < band
+        cams.append((first[s:e, None] + off)[m])
+        pts_idx.append(rows[m])
+    cam = np.concatenate(cams).astype(np.int32)
+    pt = np.concatenate(pts_idx).astype(np.int32)
+    uv, _ = project(pts_gt[pt], t_gt[cam], rpy_gt[cam])
+    uv = np.rint(uv + rng.normal(0, noise_px, uv.shape))
+    t0 = t_gt + rng.normal(0, pose_noise[0], t_gt.shape)
+    rpy0 = rpy_gt + rng.normal(0, pose_noise[1], rpy_gt.shape)
+    pts0 = pts_gt + rng.normal(0, pt_noise, pts_gt.shape)
+    return BAScene(cam=cam, pt=pt, uv=uv, t0=t0, rpy0=rpy0, pts0=pts0, t_gt=t_gt, rpy_gt=rpy_gt,
+                   pts_gt=pts_gt, K=np.array([FX, FY, CX, CY]))
+
+
+BA_CONFIGS = {
+    # name: (Nc, Np, k_mean, band)   -- BASELINE.json configs[1], [3], one 1/8 shard of [4]
+    "c1": (10, 500, 6, 10),
+    "c2": (50, 20_000, 10, 50),
+    "c4": (1_000, 500_000, 4, 16),
+    "c5shard": (10_000, 500_000, 5, 32),
+}
+
+
+def make_ba_config(name, seed=0):
+    Nc, Np, k, band = BA_CONFIGS[name]
+    return make_ba_scene(Nc, Np, k, band=band, seed=seed)
+
+
+def make_tracks_scene(n_frames=10, n_kpts=500, seed=0):
+    """A window in the reference's own containers: per-frame integer keypoints, a dense
+    frames x points track table (-1 = not seen) and float poses/points, as Tracking hands them to
+    Optimizer (src/core/tracking.cc:85-99)."""
+    sc = make_ba_scene(n_frames, n_kpts, 6, band=n_frames, seed=seed)
+    rng = np.random.default_rng(1234 + seed)
+    tracks = -np.ones((n_frames, sc.Np), np.int32)
+    keys = []
+    for f in range(n_frames):
+        obs = np.nonzero(sc.cam == f)[0]
+        perm = rng.permutation(len(obs))
+        xy = sc.uv[obs][perm].astype(np.int32)
+        extra = rng.integers(0, 200, (n_kpts - len(obs), 2)).astype(np.int32) if len(obs) < n_kpts else np.zeros((0, 2), np.int32)
+        keys.append(np.concatenate([xy, extra], axis=0))
+        tracks[f, sc.pt[obs][perm]] = np.arange(len(obs), dtype=np.int32)
+    return sc, tracks, keys
+
+
+def make_descriptors(n0=4096, n1=4096, seed=0, sigma=0.3, unmatched=0.3, duplicates=0):
+    """desc0: random unit rows; desc1: a permutation of noisy copies of desc0 (inlier rows) with
+    a fraction of unrelated rows.  `duplicates` appends exact duplicate rows to force ties."""
+    rng = np.random.default_rng(0xDE5C + seed)
+    d0 = rng.standard_normal((n0, DESC_DIM)).astype(np.float32)
+    d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    n_in = min(n0, int(round(n1 * (1.0 - unmatched))))
+    src = rng.permutation(n0)[:n_in]
+    d1 = np.empty((n1, DESC_DIM), np.float32)
+    d1[:n_in] = d0[src] + sigma / np.sqrt(DESC_DIM) * rng.standard_normal((n_in, DESC_DIM)).astype(np.float32)
+    d1[n_in:] = rng.standard_normal((n1 - n_in, DESC_DIM)).astype(np.float32)
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    d1 = d1[rng.permutation(n1)]
+    for _ in range(duplicates):
+        a, b = rng.integers(0, n1, 2)
+        d1[b] = d1[a]
+        a, b = rng.integers(0, n0, 2)
+        d0[b] = d0[a]
+    return np.ascontiguousarray(d0), np.ascontiguousarray(d1.astype(np.float32))
+
+
+def make_keypoints(n, seed=0, width=383, height=207):
+    rng = np.random.default_rng(0x4B50 + seed)
+    return np.stack([rng.integers(0, width, n), rng.integers(0, height, n)], axis=1).astype(np.int32)

@@ -1,0 +1,270 @@
+"""Benchmark of the MI355X hot path.
+
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5shard]
+
+A step = one pass of the fused residual + Jacobian + Schur linearisation (vs_ba_linearize) over
+one synthetic bundle-adjustment problem resident in HBM.  N = 1 times BASELINE.json configs[1]
+(50 keyframes, 20k landmarks, ~200k observations).  N > 1 (launched by torch.distributed.run, one
+rank per GPU) is weak scaling: N x 20k landmarks over the same 50 cameras, landmark shard r on
+rank r, and the reduced camera system summed across ranks by an RCCL all-reduce every step.
+Rank 0 prints ONE JSON line; `value` is observations/s over all ranks.  The same line carries
+`roofline` (HIP-event kernel times measured here), `cpu_baseline` (the CPU oracle timed on this
+host) and, in `extra`, the matcher leg (BASELINE.json configs[2]) and the larger BA shapes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA spec
+
+
+class _DevArray:
+    """Exposes a raw device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2}
+
+
+def fused_bytes(No, Np, Nc, nblocks):
+    """Algorithmic bytes of one fused linearisation in the fp64 layout the kernels use:
+    in : per observation camera index 4 + point index 4 + (u,v) 16; 24 per point; 48 per camera
+    out: per landmark inverse of V (sym 6) 48 + g_p 24; 288 per stored 6x6 block of S; rhs 48/camera."""
+    return 24 * No + 24 * Np + 48 * Nc + 72 * Np + 288 * nblocks + 48 * Nc
+
+
+def make_problem(name, rank, world, seed=0):
+    from visual_slam_amd import synth
+    from visual_slam_amd.ba import BAProblem
+    Nc, Np, k, band = synth.BA_CONFIGS[name]
+    sc = synth.make_ba_scene(Nc, Np * world, k, band=band, seed=seed)
+    ba = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=rank,
+                               world=world)
+    return sc, ba
+
+
+def bench_ba(args, rank, world, dist, torch):
+    t0 = time.time()
+    sc, ba = make_problem(args.workload, rank, world)
+    stream = torch.cuda.current_stream()
+    ba.set_stream(stream.cuda_stream)
+    # LM damping vectors resident in HBM (device pointers are used in place by the library)
+    dc = torch.full((6 * sc.Nc,), 1e-4, dtype=torch.float64, device="cuda")
+    dp = torch.full((3 * sc.Np,), 1e-4, dtype=torch.float64, device="cuda")
+    import ctypes as C
+    lib = ba.lib
+    pc = C.cast(C.c_void_p(dc.data_ptr()), C.POINTER(C.c_double))
+    pp = C.cast(C.c_void_p(dp.data_ptr()), C.POINTER(C.c_double))
+    assert lib.vs_ba_linearize(ba.h, pc, pp) == 0
+    ptr, n = ba.reduce_buffer()
+    red = torch.as_tensor(_DevArray(ptr, n), device="cuda") if world > 1 else None
+    setup_s = time.time() - t0
+
+    def step():
+        rc = lib.vs_ba_linearize(ba.h, pc, pp)
+        assert rc == 0
+        if world > 1:
+            dist.all_reduce(red)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    total_obs = sc.No
+    value = total_obs / (dt / args.steps)
+    out = dict(ms_per_step=ms_per_step, value=value, setup_s=setup_s, No=int(sc.No), Np=int(sc.Np),
+               Nc=int(sc.Nc))
+    if rank == 0:
+        ms = ba.profile_linearize(dc.cpu().numpy(), dp.cpu().numpy(), iters=max(20, args.steps // 2))
+        br, _ = ba.block_index()
+        local_No = sc.No // world
+        alg = fused_bytes(local_No, sc.Np // world, sc.Nc, len(br))
+        names = ["prep_cameras", "landmark", "diag(camera)", "offdiag(camera-pair)", "finalize"]
+        k_ms = {nm: float(v) for nm, v in zip(names, ms[:5])}
+        kern_sum = float(sum(ms[:5]))
+        dom = max(k_ms, key=k_ms.get)
+        achieved = alg / (kern_sum * 1e-3) / 1e9
+        out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=achieved / HBM_PEAK_GBS, traffic=None,
+                               kernel="fused linearise pipeline (5 launches)",
+                               dominant_kernel=dom, kernels_ms=k_ms, pipeline_ms=float(ms[5]),
+                               algorithmic_bytes=int(alg))
+    ba.close()
+    return out
+
+
+def bench_ba_shape(name, torch, steps=20):
+    """Single-GPU roofline of a larger BA shape (reported under extra)."""
+    sc, ba = make_problem(name, 0, 1)
+    ba.set_stream(torch.cuda.current_stream().cuda_stream)
+    dc = np.full(6 * sc.Nc, 1e-4); dp = np.full(3 * sc.Np, 1e-4)
+    ms = ba.profile_linearize(dc, dp, iters=steps)
+    br, _ = ba.block_index()
+    alg = fused_bytes(sc.No, sc.Np, sc.Nc, len(br))
+    kern = float(sum(ms[:5]))
+    ba.close()
+    names = ["prep_cameras", "landmark", "diag(camera)", "offdiag(camera-pair)", "finalize"]
+    return dict(workload=name, No=int(sc.No), Np=int(sc.Np), Nc=int(sc.Nc), n_blocks=int(len(br)),
+                obs_per_s=sc.No / (kern * 1e-3), kernels_ms={n: float(v) for n, v in zip(names, ms[:5])},
+                roofline=dict(bound="hbm", achieved=alg / (kern * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                              unit="GB/s", frac=alg / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              algorithmic_bytes=int(alg)))
+
+
+def bench_match(args, rank, world, dist, torch, n=4096, total_pairs=64):
+    from visual_slam_amd import matcher as vm
+    pairs = max(1, total_pairs // world)
+    mt = vm.Matcher(pairs, n, n)
+    mt.set_stream(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    keep = []
+    for p in range(pairs):
+        d0 = torch.randn(n, 256, device="cuda", generator=g)
+        d0 = d0 / d0.norm(dim=1, keepdim=True)
+        n_in = int(n * 0.7)
+        d1 = torch.randn(n, 256, device="cuda", generator=g)
+        src = torch.randperm(n, device="cuda", generator=g)[:n_in]
+        d1[:n_in] = d0[src] + (0.3 / 16.0) * torch.randn(n_in, 256, device="cuda", generator=g)
+        d1 = d1[torch.randperm(n, device="cuda", generator=g)]
+        d1 = (d1 / d1.norm(dim=1, keepdim=True)).contiguous()
+        keep.append((d0, d1))
+        mt.set_pair(p, (d0.data_ptr(), n), (d1.data_ptr(), n))
+    torch.cuda.synchronize()
+    steps = max(3, args.steps // 10)
+    for _ in range(2):
+        mt.run(pairs, 0.7)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        mt.run(pairs, 0.7)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    per_batch = dt / steps
+    out = dict(pairs=pairs * world, n0=n, n1=n, ms_per_batch=per_batch * 1e3,
+               query_rows_per_s=pairs * world * n / per_batch, pairs_per_s=pairs * world / per_batch)
+    if rank == 0:
+        ms = mt.profile_run(pairs, 0.7, iters=3)
+        flops = 2.0 * n * n * 256 * pairs
+        ach = flops / (float(ms[0]) * 1e-3) / 1e12
+        out["rescans_per_pair"] = mt.rescans() / pairs
+        n_match = len(mt.matches(0)[0])
+        out["matches_pair0"] = n_match
+        out["stages_ms"] = dict(zip(["dot_top2", "merge", "exact+rescan", "compact"], [float(v) for v in ms[:4]]))
+        out["roofline"] = dict(bound="mfma", achieved=ach, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                               frac=ach / MFMA_F16_PEAK_TFLOPS, traffic=None, kernel="dot_top2_kernel",
+                               note="algorithmic flops 2*N0*N1*256 per pair; the kernel issues 3x "
+                                    "that on the matrix cores (hi/lo fp16 split for fp32-accurate dots)")
+    mt.close()
+    return out
+
+
+def cpu_baseline(name):
+    """The CPU oracle (fp64, one thread) on the same BA workload: residual + Jacobian + Schur."""
+    from oracle import oracle as orc
+    from visual_slam_amd import synth
+    sc = synth.make_ba_config(name)
+    p = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    dc = np.full(6 * sc.Nc, 1e-4); dp = np.full(3 * sc.Np, 1e-4)
+    p.schur(dc=dc, dp=dp)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 20 and time.perf_counter() - t0 < 15.0:
+        p.schur(dc=dc, dp=dp)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    out = dict(value=sc.No / dt, unit="observations/s", cores=1, kind="port",
+               sample="%d passes of vo_schur (residual+Jacobian+dense-S Schur, fp64, gcc -O3) over the "
+                      "whole %s problem (%d observations)" % (reps, name, sc.No))
+    d0, d1 = synth.make_descriptors(2048, 2048, seed=0)
+    t0 = time.perf_counter()
+    orc.two_way_matching(d0, d1, 0.7)
+    dm = time.perf_counter() - t0
+    out["matcher"] = dict(value=2048 / dm * (2048.0 / 4096.0), unit="query rows/s at 4096 candidates",
+                          cores=1, kind="port", sample="one 2048x2048 pair, scaled to 4096 candidates per row")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5shard"])
+    ap.add_argument("--no-extra", action="store_true", help="skip the matcher leg and larger BA shapes")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ba = bench_ba(args, rank, world, dist, torch)
+    extra = {}
+    if not args.no_extra:
+        extra["matcher"] = bench_match(args, rank, world, dist, torch)
+        if rank == 0 and world == 1:
+            for nm in ("c4", "c5shard"):
+                if nm != args.workload:
+                    extra[nm] = bench_ba_shape(nm, torch)
+    if rank == 0:
+        line = {
+            "metric": "BA observations/sec (residual+J+Schur)",
+            "value": ba["value"], "unit": "observations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ba["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d cameras, %d landmarks, %d observations%s" % (
+                args.workload, ba["Nc"], ba["Np"], ba["No"],
+                "" if world == 1 else " (landmarks sharded over %d GPUs, RCCL all-reduce of the reduced camera system)" % world),
+                "precision": "fp64 values, int32 indices"},
+            "roofline": ba["roofline"],
+        }
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        elif not args.no_cpu:
+            line["cpu_baseline"] = None
+        line["extra"] = extra
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,7 +108,8 @@ int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double
 /* (a)+(b) fused: linearise at the current parameters and form the reduced camera system
  *   S = U + diag(damp_c) - sum_j W_j (V_j + diag(damp_p_j))^-1 W_j^T,
  *   rhs = -g_c + sum_j W_j (V_j + diag(damp_p_j))^-1 g_p_j
- * on the device (J is never materialised).  damp_c: 6*n_cameras, damp_p: 3*n_points, or NULL = 0.
+ * on the device (J is never materialised).  damp_c: 6*n_cameras, damp_p: 3*n_points, or NULL = 0;
+ * device pointers are used in place (no copy), host pointers are uploaded first.
  * This is the step the throughput metric times.  Results stay on the device. */
 int vs_ba_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p);
 /* Stored upper-triangular 6x6 blocks of S: the n_cameras diagonal blocks first, then the
@@ -138,6 +139,13 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
  * and before damping and solving; must sum `n` doubles at device pointer `buf` across ranks. */
 typedef int (*vs_allreduce_fn)(void *user, void *device_buf, int64_t n_doubles);
 int vs_ba_set_allreduce(vs_ba_handle h, vs_allreduce_fn fn, void *user);
+
+/* Measurement aid (no counterpart in the reference): runs vs_ba_linearize `iters` times with HIP
+ * events between its kernels, on the handle's stream, and returns average milliseconds:
+ * avg_ms[0..4] = camera prep, landmark pass, camera (diagonal) pass, camera-pair (off-diagonal)
+ * pass, finalize; avg_ms[5] = first event to last. */
+int vs_ba_profile_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p,
+                            int32_t iters, float *avg_ms);
 
 /* Optimizer::getPose / getPoints payloads (optimizer.cc:51-59,187-190). */
 int vs_ba_get_cameras(vs_ba_handle h, double *t, double *rpy);
@@ -177,6 +185,12 @@ int vs_matcher_get_nn(vs_matcher_handle m, int32_t pair, int32_t *idx0, int32_t 
 /* Number of rows+columns whose nearest neighbour had to be re-decided by the exact fp64 scan
  * in the last run (diagnostic). */
 int vs_matcher_get_rescans(vs_matcher_handle m, int64_t *n_rescanned);
+
+/* Measurement aid (no counterpart in the reference): vs_matcher_run `iters` times with HIP events
+ * between its stages; avg_ms[0..3] = MFMA dot + top-2 kernel, partial merge, exact distance and
+ * rescan kernels, mutual-check compaction; avg_ms[4] = first event to last. */
+int vs_matcher_profile_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float ratio,
+                           int32_t iters, float *avg_ms);
 
 /* One-shot forms with the reference's call shape (host or device pointers). */
 int vs_match_two_way(const float *desc0, int32_t n0, const float *desc1, int32_t n1,

@@ -90,6 +90,15 @@ class BAProblem:
         dp = None if damp_p is None else _f64(damp_p)
         check(self.lib.vs_ba_linearize(self.h, ptr(dc, C.c_double), ptr(dp, C.c_double)))
 
+    def profile_linearize(self, damp_c=None, damp_p=None, iters=20):
+        """Average ms of [prep, landmark, diag, offdiag, finalize, total] (HIP events)."""
+        dc = None if damp_c is None else _f64(damp_c)
+        dp = None if damp_p is None else _f64(damp_p)
+        ms = np.zeros(6, np.float32)
+        check(self.lib.vs_ba_profile_linearize(self.h, ptr(dc, C.c_double), ptr(dp, C.c_double),
+                                               int(iters), ptr(ms, C.c_float)))
+        return ms
+
     def block_index(self):
         n = C.c_int64(0)
         check(self.lib.vs_ba_block_count(self.h, C.byref(n)))

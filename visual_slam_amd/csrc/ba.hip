@@ -88,6 +88,7 @@ struct vs_ba {
     void *allreduce_user = nullptr;
 
     std::vector<int32_t> h_brow, h_bcol;
+    hipEvent_t *prof_ev = nullptr;   // when set: 6 events recorded around linearize()'s kernels
 
     DevBuf<real> t, rpy, pts, t2, rpy2, pts2;
     DevBuf<CamData> cams;
@@ -313,7 +314,10 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
 // h->red.  Point damping is applied inside (it is local to a landmark); camera damping later.
 int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDamping pd)
 {
+    auto mark = [&](int i) { if (h->prof_ev) (void)hipEventRecord(h->prof_ev[i], h->stream); };
+    mark(0);
     VS_TRY(prep_cameras(h, t, rpy));
+    mark(1);
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
         hipLaunchKernelGGL(landmark_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, h->stream,
@@ -324,6 +328,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                            h->Np, h->Nc, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
                            h->Vinv6.p, h->gp.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
     VS_TRY(launch_check("landmark_kernel"));
+    mark(2);
     if (h->n_diag_items > 0) {
         hipLaunchKernelGGL(diag_kernel, dim3(div_up(h->n_diag_items, kItemWaves)), dim3(kItemWaves * kWave), 0,
                            h->stream, h->n_diag_items, h->ditem_cam.p, h->ditem_begin.p, h->ditem_end.p, h->K,
@@ -331,6 +336,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                            (int)h->fix_points, h->Vinv6.p, h->gp.p, h->diag_partial.p);
         VS_TRY(launch_check("diag_kernel"));
     }
+    mark(3);
     if (!h->fix_points && h->n_off_items > 0) {
         hipLaunchKernelGGL(offdiag_kernel, dim3(div_up(h->n_off_items, kItemWaves)), dim3(kItemWaves * kWave), 0,
                            h->stream, h->n_off_items, h->oitem_block.p, h->oitem_begin.p, h->oitem_end.p,
@@ -338,6 +344,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                            h->Vinv6.p, h->off_partial.p);
         VS_TRY(launch_check("offdiag_kernel"));
     }
+    mark(4);
     const int nb_fin = h->fix_points ? 0 : h->nb_off;
     if (h->fix_points && h->nb_off > 0)
         VS_HIP(hipMemsetAsync(h->S_off(), 0, (size_t)h->nb_off * 36 * sizeof(real), h->stream));
@@ -346,6 +353,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                        h->ditem_ptr.p, h->diag_partial.p, h->oitem_ptr.p, h->off_partial.p, h->n_lm_blocks,
                        h->cost_partial.p, h->red.p);
     VS_TRY(launch_check("finalize_kernel"));
+    mark(5);
     h->linearized = true;
     return VS_OK;
 }
@@ -617,23 +625,71 @@ int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double
     return VS_OK;
 }
 
+// Device pointers are used in place; host pointers are uploaded first.
+static int resident_or_upload(const double *src, size_t n, DevBuf<real> &stage, hipStream_t s,
+                              const real **out)
+{
+    *out = nullptr;
+    if (!src) return VS_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeDevice) {
+        *out = src;
+        return VS_OK;
+    }
+    (void)hipGetLastError();   // an unregistered host pointer reports an error: not a failure
+    VS_TRY(stage.upload(src, n, s));
+    *out = stage.p;
+    return VS_OK;
+}
+
 int vs_ba_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p)
 {
     VS_TRY(ensure_state(h));
     hipStream_t s = h->stream;
     PointDamping pd{ nullptr, nullptr, 1.0, 0.0, 0.0 };
-    if (damp_p) {
-        VS_TRY(h->lam_p_user.upload(damp_p, 3 * (size_t)h->Np, s));
-        pd.lam_p = h->lam_p_user.p;
-    }
-    if (damp_c) VS_TRY(h->lam_c_user.upload(damp_c, 6 * (size_t)h->Nc, s));
+    const real *lc = nullptr;
+    VS_TRY(resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, s, &pd.lam_p));
+    VS_TRY(resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, s, &lc));
     VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
-    if (damp_c) {
+    if (lc) {
         hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * h->Nc, 256)), dim3(256), 0, s, h->Nc, h->udiag(),
-                           (const real *)nullptr, h->lam_c_user.p, real(1), real(0), real(0), (real *)nullptr, h->S_diag());
+                           (const real *)nullptr, lc, real(1), real(0), real(0), (real *)nullptr, h->S_diag());
         VS_TRY(launch_check("camera_damping_kernel"));
     }
     return VS_OK;
+}
+
+int vs_ba_profile_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p,
+                            int32_t iters, float *avg_ms)
+{
+    VS_TRY(ensure_state(h));
+    VS_CHECK(iters > 0 && avg_ms, VS_ERR_INVALID, "bad profiling arguments");
+    hipEvent_t ev[6];
+    for (auto &e : ev) VS_HIP(hipEventCreate(&e));
+    for (int k = 0; k < 6; k++) avg_ms[k] = 0.f;
+    int rc = vs_ba_linearize(h, damp_c, damp_p);   // warm-up
+    PointDamping pd{ nullptr, nullptr, 1.0, 0.0, 0.0 };
+    const real *lc = nullptr;
+    if (rc == VS_OK) rc = resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, h->stream, &pd.lam_p);
+    if (rc == VS_OK) rc = resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, h->stream, &lc);
+    for (int it = 0; it < iters && rc == VS_OK; it++) {
+        h->prof_ev = ev;
+        rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, pd);
+        h->prof_ev = nullptr;
+        if (rc != VS_OK) break;
+        if (hipEventSynchronize(ev[5]) != hipSuccess) { set_error("event sync failed"); rc = VS_ERR_HIP; break; }
+        for (int k = 0; k < 5; k++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            avg_ms[k] += ms;
+        }
+        float tot = 0.f;
+        (void)hipEventElapsedTime(&tot, ev[0], ev[5]);
+        avg_ms[5] += tot;
+    }
+    for (int k = 0; k < 6; k++) avg_ms[k] /= (float)iters;
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 int vs_ba_block_count(vs_ba_handle h, int64_t *n_blocks)

@@ -460,6 +460,7 @@ struct vs_matcher {
     std::vector<PairDims> h_dims;
     std::vector<unsigned char> h_masked;
     bool ran = false;
+    hipEvent_t *prof_ev = nullptr;   // when set: 6 events recorded around vs_matcher_run's stages
     DevBuf<float> d0, d1;
     DevBuf<_Float16> a_hi, a_lo, b_hi, b_lo;
     DevBuf<int2> xy0, xy1;
@@ -557,8 +558,10 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
     for (int p = 1; p < n_pairs; p++)
         VS_CHECK((bool)m->h_masked[p] == masked, VS_ERR_INVALID, "a batch must be all two-way or all stereo pairs");
     hipStream_t s = m->stream;
+    auto mark = [&](int i) { if (m->prof_ev) (void)hipEventRecord(m->prof_ev[i], s); };
     const int r0 = m->n0_pad, r1 = m->n1_pad;
     const int tiles = (r0 / kBM) * (r1 / kBN);
+    mark(0);
     const dim3 grid(tiles, 1, n_pairs);
     if (masked)
         hipLaunchKernelGGL(dot_top2_kernel<true>, grid, dim3(256), 0, s, m->a_hi.p, m->a_lo.p, m->b_hi.p, m->b_lo.p,
@@ -569,12 +572,14 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
                            m->dims.p, m->xy0.p, m->xy1.p, r0, r1, m->row_b1.p, m->row_i1.p, m->row_b2.p,
                            m->col_b1.p, m->col_i1.p, m->col_b2.p);
     VS_TRY(launch_ok("dot_top2_kernel"));
+    mark(1);
     const int force = ratio < 1.0f ? 1 : 0;   // the ratio test needs every row's exact second best
     hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0, 256), n_pairs), dim3(256), 0, s, m->dims.p, r0, r1 / kSub, 0,
                        m->row_b1.p, m->row_i1.p, m->row_b2.p, m->idx0.p, m->unc0.p, force);
     hipLaunchKernelGGL(merge_kernel, dim3(div_up(r1, 256), n_pairs), dim3(256), 0, s, m->dims.p, r1, r0 / kSub, 1,
                        m->col_b1.p, m->col_i1.p, m->col_b2.p, m->idx1.p, m->unc1.p, 0);
     VS_TRY(launch_ok("merge_kernel"));
+    mark(2);
     VS_HIP(hipMemsetAsync(m->rescan_count.p, 0, 4 * sizeof(int), s));
     const dim3 egrid(div_up(r0 + r1, 256), n_pairs);
     if (masked) {
@@ -593,11 +598,41 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
                            m->dist0.p, m->dist1.p, m->second0.p);
     }
     VS_TRY(launch_ok("exact kernels"));
+    mark(3);
     hipLaunchKernelGGL(compact_kernel, dim3(n_pairs), dim3(1024), 0, s, m->dims.p, r0, r1, m->idx0.p, m->idx1.p,
                        m->dist0.p, m->second0.p, nn_thresh, ratio, m->out_i.p, m->out_j.p, m->out_d.p, m->out_n.p);
     VS_TRY(launch_ok("compact_kernel"));
+    mark(4);
     m->ran = true;
     return VS_OK;
+}
+
+int vs_matcher_profile_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float ratio,
+                           int32_t iters, float *avg_ms)
+{
+    VS_CHECK(m && avg_ms && iters > 0, VS_ERR_INVALID, "bad profiling arguments");
+    hipEvent_t ev[5];
+    for (auto &e : ev) VS_HIP(hipEventCreate(&e));
+    for (int k = 0; k < 5; k++) avg_ms[k] = 0.f;
+    int rc = vs_matcher_run(m, n_pairs, nn_thresh, ratio);
+    for (int it = 0; it < iters && rc == VS_OK; it++) {
+        m->prof_ev = ev;
+        rc = vs_matcher_run(m, n_pairs, nn_thresh, ratio);
+        m->prof_ev = nullptr;
+        if (rc != VS_OK) break;
+        if (hipEventSynchronize(ev[4]) != hipSuccess) { set_error("event sync failed"); rc = VS_ERR_HIP; break; }
+        for (int k = 0; k < 4; k++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            avg_ms[k] += ms;
+        }
+        float tot = 0.f;
+        (void)hipEventElapsedTime(&tot, ev[0], ev[4]);
+        avg_ms[4] += tot;
+    }
+    for (int k = 0; k < 5; k++) avg_ms[k] /= (float)iters;
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 int vs_matcher_get_matches(vs_matcher_handle m, int32_t pair, int32_t *out_i, int32_t *out_j,

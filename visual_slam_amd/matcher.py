@@ -61,6 +61,13 @@ class Matcher:
     def run(self, n_pairs, nn_thresh=2.0, ratio=1.0):
         check(self.lib.vs_matcher_run(self.h, int(n_pairs), C.c_float(nn_thresh), C.c_float(ratio)))
 
+    def profile_run(self, n_pairs, nn_thresh=2.0, ratio=1.0, iters=5):
+        """Average ms of [dot+top2, merge, exact+rescan, compact, total] (HIP events)."""
+        ms = np.zeros(5, np.float32)
+        check(self.lib.vs_matcher_profile_run(self.h, int(n_pairs), C.c_float(nn_thresh),
+                                              C.c_float(ratio), int(iters), ptr(ms, C.c_float)))
+        return ms
+
     def matches(self, pair):
         n0 = max(self.sizes[int(pair)][0], 1)
         oi = np.zeros(n0, np.int32); oj = np.zeros(n0, np.int32); od = np.zeros(n0, np.float32)

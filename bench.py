@@ -101,7 +101,7 @@ def bench_ba(args, rank, world, dist, torch):
         br, _ = ba.block_index()
         local_No = sc.No // world
         alg = fused_bytes(local_No, sc.Np // world, sc.Nc, len(br))
-        names = ["prep_cameras", "landmark", "diag(camera)", "offdiag(camera-pair)", "finalize"]
+        names = ["prep_cameras", "landmark", "blocks(camera+camera-pair)", "(unused)", "finalize"]
         k_ms = {nm: float(v) for nm, v in zip(names, ms[:5])}
         kern_sum = float(sum(ms[:5]))
         dom = max(k_ms, key=k_ms.get)
@@ -125,7 +125,7 @@ def bench_ba_shape(name, torch, steps=20):
     alg = fused_bytes(sc.No, sc.Np, sc.Nc, len(br))
     kern = float(sum(ms[:5]))
     ba.close()
-    names = ["prep_cameras", "landmark", "diag(camera)", "offdiag(camera-pair)", "finalize"]
+    names = ["prep_cameras", "landmark", "blocks(camera+camera-pair)", "(unused)", "finalize"]
     return dict(workload=name, No=int(sc.No), Np=int(sc.Np), Nc=int(sc.Nc), n_blocks=int(len(br)),
                 obs_per_s=sc.No / (kern * 1e-3), kernels_ms={n: float(v) for n, v in zip(names, ms[:5])},
                 roofline=dict(bound="hbm", achieved=alg / (kern * 1e-3) / 1e9, peak=HBM_PEAK_GBS,

@@ -2,6 +2,7 @@
 // the Levenberg-Marquardt loop.  Reference interfaces replaced are cited in include/vslam_hip.h.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -81,7 +82,7 @@ struct vs_ba {
     bool have_scale = false;
     int rank = 0, world = 1;
     HuberObs hub{ -1, -1, -1, 0.0 };
-    int nb_off = 0, n_diag_items = 0, n_off_items = 0, n_lm_blocks = 0;
+    int nb_off = 0, n_diag_items = 0, n_off_items = 0, n_lm_blocks = 0, n_lm4_blocks = 0, item_waves = 4;
     bool stage_cams = false;
     int64_t red_len = 0;
     vs_allreduce_fn allreduce = nullptr;
@@ -92,11 +93,11 @@ struct vs_ba {
 
     DevBuf<real> t, rpy, pts, t2, rpy2, pts2;
     DevBuf<CamData> cams;
-    DevBuf<int> pt_ptr, lcam, lpt, lobs, cam_ptr, cobs, brow, bcol, bent;
-    DevBuf<int> ditem_cam, ditem_begin, ditem_end, ditem_ptr;
-    DevBuf<int> oitem_block, oitem_begin, oitem_end, oitem_ptr;
+    DevBuf<int> pt_ptr, lcam, lpt, lobs, cam_ptr, cpt, brow, bcol, bent;
+    DevBuf<int> ditem_ptr, oitem_ptr;
+    DevBuf<BlockItem> items;
     DevBuf<unsigned char> cam_used, pt_used;
-    DevBuf<real> luv, Vinv6, gp, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
+    DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
     DevBuf<real> scale_c, scale_p, lam_c, lam_c_user, lam_p_user, dcam, dpt, mcc_partial,
         cand_partial, scalars, dense, linv;
     DevBuf<int> info;
@@ -238,41 +239,52 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         }
     }
     // camera-major view of the local observations
-    std::vector<int> cam_ptr((size_t)Nc + 1, 0), cobs((size_t)std::max(No, 1));
+    std::vector<int> cam_ptr((size_t)Nc + 1, 0), cpt((size_t)std::max(No, 1));
+    std::vector<real> cuv((size_t)std::max(No, 1) * 2);
     for (int p = 0; p < No; p++) cam_ptr[lcam[p] + 1]++;
     for (int c = 0; c < Nc; c++) cam_ptr[c + 1] += cam_ptr[c];
     {
         std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
-        for (int p = 0; p < No; p++) cobs[fill[lcam[p]]++] = p;
-    }
-    // work items: chunks sized so that the grid holds a few thousand waves
-    auto chunk_of = [](int64_t total) {
-        int64_t c = (total / 4096 + 63) / 64 * 64;
-        return (int)std::min<int64_t>(std::max<int64_t>(c, 64), 1024);
-    };
-    std::vector<int> di_cam, di_b, di_e, di_ptr((size_t)Nc + 1, 0);
-    {
-        const int ch = chunk_of(No);
-        for (int c = 0; c < Nc; c++) {
-            for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += ch) {
-                di_cam.push_back(c); di_b.push_back(b); di_e.push_back(std::min(b + ch, cam_ptr[c + 1]));
-            }
-            di_ptr[c + 1] = (int)di_cam.size();
+        for (int p = 0; p < No; p++) {
+            const int k = fill[lcam[p]]++;
+            cpt[k] = lpt[p]; cuv[2 * (size_t)k] = luv[2 * (size_t)p]; cuv[2 * (size_t)k + 1] = luv[2 * (size_t)p + 1];
         }
     }
-    std::vector<int> oi_blk, oi_b, oi_e, oi_ptr((size_t)nb_off + 1, 0);
+    // work items: one workgroup each, ~3 entries per thread; 4 waves per item when the typical
+    // block is large, else 1.  Blocks that fit one item are written by the block kernel directly,
+    // the others go through partials + finalize.
     {
-        const int ch = chunk_of(n_ent);
-        for (int k = 0; k < nb_off; k++) {
-            for (int b = bptr[k]; b < bptr[k + 1]; b += ch) {
-                oi_blk.push_back(k); oi_b.push_back(b); oi_e.push_back(std::min(b + ch, bptr[k + 1]));
-            }
-            oi_ptr[k + 1] = (int)oi_blk.size();
-        }
+        int64_t nb_used = 0, nc_used = 0;
+        for (int c = 0; c < Nc; c++) nc_used += cam_ptr[c + 1] > cam_ptr[c];
+        for (int k = 0; k < nb_off; k++) nb_used += bptr[k + 1] > bptr[k];
+        const double avg = nb_used ? double(n_ent) / double(nb_used) : (nc_used ? double(No) / double(nc_used) : 0.0);
+        h->item_waves = avg >= 512.0 ? 4 : 1;
     }
-    h->n_diag_items = (int)di_cam.size();
-    h->n_off_items = (int)oi_blk.size();
+    int ept = 3;                                           // entries per thread and item
+    if (const char *e = getenv("VS_BA_ITEM_WAVES")) h->item_waves = atoi(e) == 4 ? 4 : 1;   // tuning knobs
+    if (const char *e = getenv("VS_BA_ITEM_EPT")) ept = std::max(1, atoi(e));
+    const int ch = h->item_waves * kWave * ept;
+    std::vector<BlockItem> items;
+    std::vector<int> di_ptr((size_t)Nc + 1, 0), oi_ptr((size_t)nb_off + 1, 0);
+    for (int c = 0; c < Nc; c++) {
+        const size_t first = items.size();
+        for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += ch)
+            items.push_back(BlockItem{ c, b, std::min(b + ch, cam_ptr[c + 1]), c, c, 0, 0, 0 });
+        di_ptr[c + 1] = (int)items.size();
+        if (items.size() - first == 1) items[first].single = 1;
+    }
+    const int n_diag_items = (int)items.size();
+    for (int k = 0; k < nb_off; k++) {
+        const size_t first = items.size();
+        for (int b = bptr[k]; b < bptr[k + 1]; b += ch)
+            items.push_back(BlockItem{ k, b, std::min(b + ch, bptr[k + 1]), h->h_brow[k], h->h_bcol[k], 0, 0, 0 });
+        oi_ptr[k + 1] = (int)items.size() - n_diag_items;
+        if (items.size() - first == 1) items[first].single = 1;
+    }
+    h->n_diag_items = n_diag_items;
+    h->n_off_items = (int)items.size() - n_diag_items;
     h->n_lm_blocks = div_up(Np, kLmThreads);
+    h->n_lm4_blocks = div_up(Np, kLmPerBlock);
     h->stage_cams = (size_t)Nc * sizeof(CamData) <= 48 * 1024;
 
     hipStream_t s = h->stream;
@@ -282,7 +294,8 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     VS_TRY(h->lobs.upload(lobs.data(), lobs.size(), s));
     VS_TRY(h->luv.upload(luv.data(), luv.size(), s));
     VS_TRY(h->cam_ptr.upload(cam_ptr.data(), cam_ptr.size(), s));
-    VS_TRY(h->cobs.upload(cobs.data(), cobs.size(), s));
+    VS_TRY(h->cpt.upload(cpt.data(), cpt.size(), s));
+    VS_TRY(h->cuv.upload(cuv.data(), cuv.size(), s));
     VS_TRY(h->cam_used.upload(cam_used.data(), cam_used.size(), s));
     VS_TRY(h->pt_used.upload(pt_used.data(), pt_used.size(), s));
     std::vector<int> one(1, 0);
@@ -290,13 +303,12 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     VS_TRY(h->bcol.upload(nb_off ? h->h_bcol.data() : one.data(), std::max(nb_off, 1), s));
     VS_TRY(h->bent.upload(bent.data(), bent.size(), s));
     auto up = [&](DevBuf<int> &d, std::vector<int> &v) { if (v.empty()) v.push_back(0); return d.upload(v.data(), v.size(), s); };
-    VS_TRY(up(h->ditem_cam, di_cam)); VS_TRY(up(h->ditem_begin, di_b)); VS_TRY(up(h->ditem_end, di_e));
-    VS_TRY(up(h->ditem_ptr, di_ptr));
-    VS_TRY(up(h->oitem_block, oi_blk)); VS_TRY(up(h->oitem_begin, oi_b)); VS_TRY(up(h->oitem_end, oi_e));
-    VS_TRY(up(h->oitem_ptr, oi_ptr));
+    VS_TRY(up(h->ditem_ptr, di_ptr)); VS_TRY(up(h->oitem_ptr, oi_ptr));
+    if (items.empty()) items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
+    VS_TRY(h->items.upload(items.data(), items.size(), s));
     VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
     VS_TRY(h->off_partial.alloc((size_t)std::max(h->n_off_items, 1) * kOffVals));
-    VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
+    VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm4_blocks, 1)));
     VS_TRY(h->mcc_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
     h->red_len = (int64_t)Nc * 36 + (int64_t)nb_off * 36 + 18 * (int64_t)Nc + 1;
     VS_TRY(h->red.alloc((size_t)h->red_len));
@@ -320,37 +332,40 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     mark(1);
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
-        hipLaunchKernelGGL(landmark_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, h->stream,
+        hipLaunchKernelGGL(landmark_kernel<true>, dim3(h->n_lm4_blocks), dim3(kLmThreads), lds, h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
-                           h->Vinv6.p, h->gp.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+                           h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
     else
-        hipLaunchKernelGGL(landmark_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, h->stream,
+        hipLaunchKernelGGL(landmark_kernel<false>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
-                           h->Vinv6.p, h->gp.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+                           h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
     VS_TRY(launch_check("landmark_kernel"));
     mark(2);
-    if (h->n_diag_items > 0) {
-        hipLaunchKernelGGL(diag_kernel, dim3(div_up(h->n_diag_items, kItemWaves)), dim3(kItemWaves * kWave), 0,
-                           h->stream, h->n_diag_items, h->ditem_cam.p, h->ditem_begin.p, h->ditem_end.p, h->K,
-                           h->cams.p, pts, h->cobs.p, h->lpt.p, h->luv.p, h->hub, h->hub_w.p,
-                           (int)h->fix_points, h->Vinv6.p, h->gp.p, h->diag_partial.p);
-        VS_TRY(launch_check("diag_kernel"));
+    {
+        // with fixed points only the camera (diagonal) items run
+        const int n_items = h->n_diag_items + (h->fix_points ? 0 : h->n_off_items);
+        if (n_items > 0) {
+            if (h->item_waves == 4)
+                hipLaunchKernelGGL(blocks_kernel<4>, dim3(n_items), dim3(4 * kWave), 0, h->stream, h->n_diag_items,
+                                   h->items.p, h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
+                                   h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
+                                   h->Nc, h->nb_off);
+            else
+                hipLaunchKernelGGL(blocks_kernel<1>, dim3(n_items), dim3(kWave), 0, h->stream, h->n_diag_items,
+                                   h->items.p, h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
+                                   h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
+                                   h->Nc, h->nb_off);
+            VS_TRY(launch_check("blocks_kernel"));
+        }
     }
     mark(3);
-    if (!h->fix_points && h->n_off_items > 0) {
-        hipLaunchKernelGGL(offdiag_kernel, dim3(div_up(h->n_off_items, kItemWaves)), dim3(kItemWaves * kWave), 0,
-                           h->stream, h->n_off_items, h->oitem_block.p, h->oitem_begin.p, h->oitem_end.p,
-                           h->brow.p, h->bcol.p, h->K, h->cams.p, pts, h->bent.p, h->hub, h->hub_w.p,
-                           h->Vinv6.p, h->off_partial.p);
-        VS_TRY(launch_check("offdiag_kernel"));
-    }
     mark(4);
     const int nb_fin = h->fix_points ? 0 : h->nb_off;
     if (h->fix_points && h->nb_off > 0)
         VS_HIP(hipMemsetAsync(h->S_off(), 0, (size_t)h->nb_off * 36 * sizeof(real), h->stream));
-    const int64_t n_fin = (int64_t)h->Nc * kDiagVals + (int64_t)nb_fin * kOffVals + 1;
-    hipLaunchKernelGGL(finalize_kernel, dim3(div_up(n_fin, 256)), dim3(256), 0, h->stream, h->Nc, h->nb_off, nb_fin,
-                       h->ditem_ptr.p, h->diag_partial.p, h->oitem_ptr.p, h->off_partial.p, h->n_lm_blocks,
+    const int64_t n_fin = (int64_t)h->Nc * kDiagVals + (int64_t)nb_fin * kOffVals;
+    hipLaunchKernelGGL(finalize_kernel, dim3(div_up(n_fin, 256) + 1), dim3(256), 0, h->stream, h->Nc, h->nb_off, nb_fin,
+                       h->ditem_ptr.p, h->diag_partial.p, h->oitem_ptr.p, h->off_partial.p, h->n_lm4_blocks,
                        h->cost_partial.p, h->red.p);
     VS_TRY(launch_check("finalize_kernel"));
     mark(5);
@@ -426,11 +441,11 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
     if (h->stage_cams)
         hipLaunchKernelGGL(backsub_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
                            h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p,
-                           (int)h->fix_points, h->Vinv6.p, h->gp.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
+                           (int)h->fix_points, h->lmrec.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
     else
         hipLaunchKernelGGL(backsub_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, Np, Nc, h->K,
                            h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p,
-                           (int)h->fix_points, h->Vinv6.p, h->gp.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
+                           (int)h->fix_points, h->lmrec.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
     VS_TRY(launch_check("backsub_kernel"));
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->mcc_partial.p, h->scalars.p);
     const int64_t npar = 6 * (int64_t)Nc + 3 * (int64_t)Np;
@@ -473,7 +488,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
 int gradient_max(vs_ba *h, real *out)
 {
     hipLaunchKernelGGL(gradient_max_kernel, dim3(1), dim3(256), 0, h->stream, (int64_t)6 * h->Nc, h->gc(),
-                       h->fix_points ? (int64_t)0 : 3 * (int64_t)h->Np, h->gp.p, h->scalars.p + 4);
+                       h->fix_points ? (int64_t)0 : 3 * (int64_t)h->Np, h->lmrec.p, h->scalars.p + 4);
     VS_TRY(launch_check("gradient_max_kernel"));
     VS_HIP(hipMemcpyAsync(out, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, h->stream));
     VS_HIP(hipStreamSynchronize(h->stream));
@@ -518,7 +533,7 @@ int vs_ba_create(vs_ba_handle *out, int32_t Nc, int32_t Np, int64_t No, double f
     A(h->t.alloc(3 * (size_t)Nc)); A(h->rpy.alloc(3 * (size_t)Nc)); A(h->pts.alloc(3 * (size_t)Np));
     A(h->t2.alloc(3 * (size_t)Nc)); A(h->rpy2.alloc(3 * (size_t)Nc)); A(h->pts2.alloc(3 * (size_t)Np));
     A(h->cams.alloc((size_t)Nc));
-    A(h->Vinv6.alloc(6 * (size_t)Np)); A(h->gp.alloc(3 * (size_t)Np)); A(h->Vdiag.alloc(3 * (size_t)Np));
+    A(h->lmrec.alloc((size_t)kRec * Np)); A(h->Vdiag.alloc(3 * (size_t)Np));
     A(h->hub_w.alloc(1)); A(h->scale_c.alloc(6 * (size_t)Nc)); A(h->scale_p.alloc(3 * (size_t)Np));
     A(h->lam_c.alloc(6 * (size_t)Nc)); A(h->dcam.alloc(6 * (size_t)Nc)); A(h->dpt.alloc(3 * (size_t)Np));
     A(h->scalars.alloc(8)); A(h->info.alloc(1)); A(h->linv.alloc(kNB * kNB));
@@ -726,8 +741,9 @@ int vs_ba_get_landmark_blocks(vs_ba_handle h, double *Vinv6, double *gp)
     VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
     VS_CHECK(h->linearized, VS_ERR_STATE, "call vs_ba_linearize first");
     hipStream_t s = h->stream;
-    if (Vinv6) VS_HIP(hipMemcpyAsync(Vinv6, h->Vinv6.p, 6 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, s));
-    if (gp) VS_HIP(hipMemcpyAsync(gp, h->gp.p, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, s));
+    const size_t pitch = kRec * sizeof(real);
+    if (Vinv6) VS_HIP(hipMemcpy2DAsync(Vinv6, 6 * sizeof(real), h->lmrec.p + 3, pitch, 6 * sizeof(real), (size_t)h->Np, hipMemcpyDefault, s));
+    if (gp) VS_HIP(hipMemcpy2DAsync(gp, 3 * sizeof(real), h->lmrec.p + 9, pitch, 3 * sizeof(real), (size_t)h->Np, hipMemcpyDefault, s));
     VS_HIP(hipStreamSynchronize(s));
     return VS_OK;
 }

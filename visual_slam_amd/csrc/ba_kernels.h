@@ -34,7 +34,6 @@ struct Intr {
 
 constexpr int kWave = 64;
 constexpr int kLmThreads = 256;   // landmark-major kernels: one thread per landmark
-constexpr int kItemWaves = 4;     // block-major kernels: one wave per work item
 constexpr int kRedStride = 65;    // padded row of the transposed wave reduction (conflict-free)
 constexpr int kDiagVals = 39;     // S_cc sym 21 | rhs 6 | diag(U) 6 | g_c 6
 constexpr int kOffVals = 36;      // S_ab 6x6
@@ -195,15 +194,22 @@ struct HuberObs {
     real a;         // Huber parameter
 };
 
-// (a)+(b), landmark side.  One thread per landmark j: V_j = sum Jp^T Jp, g_p_j = sum Jp^T r,
-// cost, then Vinv_j = (V_j + damping)^-1.  Cameras come from LDS when they fit (STAGE_CAMS).
+// Per-landmark record written by the landmark kernel and read by the block and
+// back-substitution kernels: P[3], inverse of the damped V (xx,xy,xz,yy,yz,zz), g_p[3].
+constexpr int kRec = 12;
+constexpr int kLpl = 4;                               // lanes cooperating on one landmark
+constexpr int kLmPerBlock = kLmThreads / kLpl;        // landmarks per workgroup
+
+// (a)+(b), landmark side.  Four lanes per landmark j share its observations:
+// V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
+// Cameras come from LDS when they fit (STAGE_CAMS).
 template <bool STAGE_CAMS>
 __global__ void __launch_bounds__(kLmThreads)
 landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                 const real *__restrict__ pts, const int *__restrict__ pt_ptr,
                 const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
-                PointDamping damp, real *__restrict__ Vinv6, real *__restrict__ gp,
-                real *__restrict__ Vdiag, real *__restrict__ hub_w, real *__restrict__ cost_partial)
+                PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
+                real *__restrict__ hub_w, real *__restrict__ cost_partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     CamData *scams = reinterpret_cast<CamData *>(smem_raw);
@@ -214,13 +220,17 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
         for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    real cost = real(0);
+    const int j = blockIdx.x * kLmPerBlock + ((int)threadIdx.x >> 2);
+    const int sl = threadIdx.x & (kLpl - 1);
+    real acc[10];                                      // V (6), g (3), cost
+#pragma unroll
+    for (int v = 0; v < 10; v++) acc[v] = real(0);
+    real P[3] = { 0, 0, 0 };
+    int b = 0, e = 0;
     if (j < Np) {
-        const int b = pt_ptr[j], e = pt_ptr[j + 1];
-        const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
-        real V[6] = { 0, 0, 0, 0, 0, 0 }, g[3] = { 0, 0, 0 };
-        for (int pos = b; pos < e; pos++) {
+        b = pt_ptr[j]; e = pt_ptr[j + 1];
+        P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
+        for (int pos = b + sl; pos < e; pos += kLpl) {
             const int c = lcam[pos];
             CamData cd;
             if (STAGE_CAMS) cd = scams[c]; else load_cam(cams, c, cd);
@@ -232,19 +242,30 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                 scale_lin(o, w);
                 *hub_w = w;
             }
-            cost += hr;
+            acc[9] += hr;
             real Jp[6];
             point_jac(cd, o, Jp);
-            V[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
-            V[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
-            V[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
-            V[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4];
-            V[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5];
-            V[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
-            g[0] += Jp[0] * o.r0 + Jp[3] * o.r1;
-            g[1] += Jp[1] * o.r0 + Jp[4] * o.r1;
-            g[2] += Jp[2] * o.r0 + Jp[5] * o.r1;
+            acc[0] = fma(Jp[0], Jp[0], fma(Jp[3], Jp[3], acc[0]));
+            acc[1] = fma(Jp[0], Jp[1], fma(Jp[3], Jp[4], acc[1]));
+            acc[2] = fma(Jp[0], Jp[2], fma(Jp[3], Jp[5], acc[2]));
+            acc[3] = fma(Jp[1], Jp[1], fma(Jp[4], Jp[4], acc[3]));
+            acc[4] = fma(Jp[1], Jp[2], fma(Jp[4], Jp[5], acc[4]));
+            acc[5] = fma(Jp[2], Jp[2], fma(Jp[5], Jp[5], acc[5]));
+            acc[6] = fma(Jp[0], o.r0, fma(Jp[3], o.r1, acc[6]));
+            acc[7] = fma(Jp[1], o.r0, fma(Jp[4], o.r1, acc[7]));
+            acc[8] = fma(Jp[2], o.r0, fma(Jp[5], o.r1, acc[8]));
         }
+    }
+    // fixed-order sum over the 4 cooperating lanes (every lane ends with the same totals)
+#pragma unroll
+    for (int v = 0; v < 10; v++) {
+        acc[v] += __shfl_xor(acc[v], 1, 64);
+        acc[v] += __shfl_xor(acc[v], 2, 64);
+    }
+    real cost = real(0);
+    if (j < Np && sl == 0) {
+        cost = acc[9];
+        const real *V = acc;
         if (Vdiag) { Vdiag[3 * j] = V[0]; Vdiag[3 * j + 1] = V[3]; Vdiag[3 * j + 2] = V[5]; }
         real vi[6] = { 0, 0, 0, 0, 0, 0 };
         if (e > b) {
@@ -271,10 +292,13 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
             vi[3] = (a * f - cc * cc) * id; vi[4] = (bb * cc - a * ee) * id;
             vi[5] = (a * d - bb * bb) * id;
         }
-#pragma unroll
-        for (int k = 0; k < 6; k++) Vinv6[6 * j + k] = vi[k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) gp[3 * j + k] = g[k];
+        double2 *rec = reinterpret_cast<double2 *>(lmrec + (int64_t)kRec * j);
+        rec[0] = make_double2(P[0], P[1]);
+        rec[1] = make_double2(P[2], vi[0]);
+        rec[2] = make_double2(vi[1], vi[2]);
+        rec[3] = make_double2(vi[3], vi[4]);
+        rec[4] = make_double2(vi[5], acc[6]);
+        rec[5] = make_double2(acc[7], acc[8]);
     }
     const real s = block_sum_256(cost, red);
     if (threadIdx.x == 0) cost_partial[blockIdx.x] = s;
@@ -370,190 +394,289 @@ __device__ __forceinline__ real wave_reduce_transposed(const real *acc, real *ld
     return s;
 }
 
-// (a)+(b), camera side.  One wave per work item = a slice [begin,end) of one camera's
-// observations (camera-major view).  Per observation: recompute r, Jc, Jp, W = Jc^T Jp and
-// accumulate  S_cc += Jc^T Jc - W Vinv W^T (sym, 21), rhs += -Jc^T r + W Vinv g_p,
-// diag(U) += diag(Jc^T Jc), g_c += Jc^T r.  With fix_points the Schur terms are skipped.
-__global__ void __launch_bounds__(kItemWaves *kWave)
-diag_kernel(int n_items, const int *__restrict__ item_cam, const int *__restrict__ item_begin,
-            const int *__restrict__ item_end, Intr K, const CamData *__restrict__ cams,
-            const real *__restrict__ pts, const int *__restrict__ cobs,
-            const int *__restrict__ lpt, const real *__restrict__ luv, HuberObs hub,
-            const real *__restrict__ hub_w, int fix_points, const real *__restrict__ Vinv6,
-            const real *__restrict__ gp, real *__restrict__ partial /* n_items x kDiagVals */)
+// Views into the reduce buffer
+//   [ S_diag Nc x 36 | S_off nb_off x 36 | rhs 6Nc | diag(U) 6Nc | g_c 6Nc | cost ].
+struct RedView {
+    real *S_diag, *S_off, *rhs, *udiag, *gc, *cost;
+};
+__host__ __device__ __forceinline__ RedView red_view(real *red, int Nc, int nb_off)
 {
-    __shared__ real red[kItemWaves * 21 * kRedStride];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * kItemWaves + wave;
-    real acc[kDiagVals];
-#pragma unroll
-    for (int v = 0; v < kDiagVals; v++) acc[v] = real(0);
-    if (item < n_items) {
-        const int c = item_cam[item];
-        const int b = item_begin[item], e = item_end[item];
-        CamData cd;
-        load_cam(cams, c, cd);
-        for (int k = b + lane; k < e; k += kWave) {
-            const int pos = cobs[k];
-            const int j = lpt[pos];
-            const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
-            ObsLin o;
-            project_obs(cd, P, luv[2 * pos], luv[2 * pos + 1], K, o);
-            if (pos == hub.pos) scale_lin(o, *hub_w);
-            real Jc[12];
-            camera_jac(cd, o, P, Jc);
-            // S_cc upper triangle (21), starting from U
-            int idx = 0;
-#pragma unroll
-            for (int p = 0; p < 6; p++)
-#pragma unroll
-                for (int q = p; q < 6; q++) acc[idx++] += Jc[p] * Jc[q] + Jc[6 + p] * Jc[6 + q];
-            real gc[6];
-#pragma unroll
-            for (int p = 0; p < 6; p++) {
-                gc[p] = Jc[p] * o.r0 + Jc[6 + p] * o.r1;
-                acc[21 + p] -= gc[p];
-                acc[27 + p] += Jc[p] * Jc[p] + Jc[6 + p] * Jc[6 + p];
-                acc[33 + p] += gc[p];
-            }
-            if (!fix_points) {
-                real Jp[6], W[18], Z[18], vi[6];
-                point_jac(cd, o, Jp);
-                w_block(Jc, Jp, W);
-#pragma unroll
-                for (int m = 0; m < 6; m++) vi[m] = Vinv6[6 * j + m];
-                z_block(W, vi, Z);
-                const real g0 = gp[3 * j], g1 = gp[3 * j + 1], g2 = gp[3 * j + 2];
-                idx = 0;
-#pragma unroll
-                for (int p = 0; p < 6; p++) {
-#pragma unroll
-                    for (int q = p; q < 6; q++)
-                        acc[idx++] -= Z[3 * p] * W[3 * q] + Z[3 * p + 1] * W[3 * q + 1] +
-                                      Z[3 * p + 2] * W[3 * q + 2];
-                    acc[21 + p] += Z[3 * p] * g0 + Z[3 * p + 1] * g1 + Z[3 * p + 2] * g2;
-                }
-            }
-        }
-    }
-    real *lds_wave = red + wave * 21 * kRedStride;
-    const real s1 = wave_reduce_transposed<21>(acc, lds_wave, lane);
-    const real s2 = wave_reduce_transposed<18>(acc + 21, lds_wave, lane);
-    if (item < n_items) {
-        if (lane < 21) partial[(int64_t)item * kDiagVals + lane] = s1;
-        if (lane < 18) partial[(int64_t)item * kDiagVals + 21 + lane] = s2;
-    }
+    RedView r;
+    r.S_diag = red;
+    r.S_off = r.S_diag + (int64_t)Nc * 36;
+    r.rhs = r.S_off + (int64_t)nb_off * 36;
+    r.udiag = r.rhs + 6 * (int64_t)Nc;
+    r.gc = r.udiag + 6 * (int64_t)Nc;
+    r.cost = r.gc + 6 * (int64_t)Nc;
+    return r;
 }
 
-// (b) off-diagonal camera-pair blocks.  One wave per work item = a slice of the landmarks seen
-// by both cameras (a < b) of one block:  S_ab -= W_a Vinv W_b^T, with W recomputed from the
-// landmark position and the two (wave-uniform) cameras.
-__global__ void __launch_bounds__(kItemWaves *kWave)
-offdiag_kernel(int n_items, const int *__restrict__ item_block, const int *__restrict__ item_begin,
-               const int *__restrict__ item_end, const int *__restrict__ brow,
-               const int *__restrict__ bcol, Intr K, const CamData *__restrict__ cams,
-               const real *__restrict__ pts, const int *__restrict__ bent, HuberObs hub,
-               const real *__restrict__ hub_w, const real *__restrict__ Vinv6,
-               real *__restrict__ partial /* n_items x kOffVals */)
+// value v of camera c's 39 sums: [0,21) upper triangle of S_cc, [21,27) rhs, [27,33) diag(U),
+// [33,39) g_c
+__device__ __forceinline__ void store_diag_value(const RedView &rv, int c, int v, real s)
 {
-    __shared__ real red[kItemWaves * 18 * kRedStride];
+    if (v < 21) {
+        int p = 0, rem = v;
+        while (rem >= 6 - p) { rem -= 6 - p; p++; }
+        const int q = p + rem;
+        rv.S_diag[(int64_t)c * 36 + 6 * p + q] = s;
+        rv.S_diag[(int64_t)c * 36 + 6 * q + p] = s;
+    } else if (v < 27) rv.rhs[6 * c + v - 21] = s;
+    else if (v < 33) rv.udiag[6 * c + v - 27] = s;
+    else rv.gc[6 * c + v - 33] = s;
+}
+
+// Workgroup-wide fixed-order sum of NV per-thread values: per-wave transposed reduction, then
+// the waves' sums are added in wave order.  Result valid in wave 0, lanes < NV.
+template <int NV, int WAVES>
+__device__ __forceinline__ real group_reduce(const real *acc, real *lds_wave, real *xw, int lane,
+                                             int wave)
+{
+    real s = wave_reduce_transposed<NV>(acc, lds_wave, lane);
+    if (WAVES > 1) {
+        if (lane < NV) xw[wave * 24 + lane] = s;
+        __syncthreads();
+        if (wave == 0 && lane < NV) {
+            s = xw[lane];
+#pragma unroll
+            for (int w = 1; w < WAVES; w++) s += xw[w * 24 + lane];
+        }
+    }
+    return s;
+}
+
+// One work item of the block kernel (32 bytes, read through the scalar cache).
+struct BlockItem {
+    int blk;        // camera (diagonal item) or off-diagonal block id
+    int begin, end; // entry range: camera-major observations, or camera-pair entries
+    int ca, cb;     // the block's cameras (ca == cb for a diagonal item)
+    int single;     // the block consists of this item only: write the final values directly
+    int pad0, pad1;
+};
+static_assert(sizeof(BlockItem) == 32, "BlockItem is 32 bytes");
+
+__device__ __forceinline__ void load_rec(const real *__restrict__ lmrec, int j, real *r, int n2)
+{
+    const double2 *src = reinterpret_cast<const double2 *>(lmrec + (int64_t)kRec * j);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+        if (i < n2) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+}
+
+// (a)+(b), block side: one workgroup of WAVES waves per work item.
+//   items [0, n_diag_items): a slice of one camera's observations (camera-major view).  Per
+//     observation, with N = I - Jp Vinv Jp^T (2x2; N = I when points are fixed):
+//       S_cc += Jc^T N Jc,  rhs += Jc^T (Jp Vinv g_p - r),  diag(U) += diag(Jc^T Jc),  g_c += Jc^T r
+//   items [n_diag_items, n_items): a slice of the landmarks seen by both cameras a < b of one
+//     off-diagonal block:  S_ab -= Jc_a^T (Jp_a Vinv Jp_b^T) Jc_b.
+// r, Jc, Jp are recomputed from the parameters (J is never stored).  The next entry's landmark
+// record is loaded while the current one is processed.  A block made of a single item is written
+// straight into the reduce buffer, otherwise a per-item partial is written and finalize_kernel
+// adds the partials in item order.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES *kWave)
+blocks_kernel(int n_diag_items, const BlockItem *__restrict__ items, Intr K,
+              const CamData *__restrict__ cams, const real *__restrict__ lmrec,
+              const int *__restrict__ cpt, const real *__restrict__ cuv,
+              const int *__restrict__ bent, HuberObs hub, const real *__restrict__ hub_w,
+              int fix_points, real *__restrict__ diag_partial, real *__restrict__ off_partial,
+              real *red, int Nc, int nb_off)
+{
+    __shared__ real lds[WAVES * 21 * kRedStride + WAVES * 24];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * kItemWaves + wave;
-    real acc[kOffVals];
+    real *lds_wave = lds + wave * 21 * kRedStride;
+    real *xw = lds + WAVES * 21 * kRedStride;
+    const int item = blockIdx.x;
+    const BlockItem it = items[item];
+    const RedView rv = red_view(red, Nc, nb_off);
+    constexpr int kStride = WAVES * kWave;
+    if (item < n_diag_items) {
+        real acc[kDiagVals];
 #pragma unroll
-    for (int v = 0; v < kOffVals; v++) acc[v] = real(0);
-    if (item < n_items) {
-        const int blk = item_block[item];
-        const int ca = brow[blk], cb = bcol[blk];
-        const int b = item_begin[item], e = item_end[item];
+        for (int v = 0; v < kDiagVals; v++) acc[v] = real(0);
+        CamData cd;
+        load_cam(cams, it.ca, cd);
+        int k = it.begin + (int)threadIdx.x;
+        bool have = k < it.end;
+        real rec[kRec], u = 0, vv = 0;
+        int j = 0;
+        if (have) { j = cpt[k]; u = cuv[2 * k]; vv = cuv[2 * k + 1]; load_rec(lmrec, j, rec, 6); }
+        while (have) {
+            const int kn = k + kStride;
+            const bool hn = kn < it.end;
+            real recn[kRec], un = 0, vn = 0;
+            int jn = 0;
+            if (hn) { jn = cpt[kn]; un = cuv[2 * kn]; vn = cuv[2 * kn + 1]; load_rec(lmrec, jn, recn, 6); }
+            const real *P = rec, *vi = rec + 3, *g = rec + 9;
+            ObsLin o;
+            project_obs(cd, P, u, vv, K, o);
+            if (j == hub.pt && it.ca == hub.cam) scale_lin(o, *hub_w);
+            real Jc[12];
+            camera_jac(cd, o, P, Jc);
+            real n00 = real(1), n01 = real(0), n11 = real(1), e0 = -o.r0, e1 = -o.r1;
+            if (!fix_points) {
+                real Jp[6], T[6];
+                point_jac(cd, o, Jp);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    T[3 * r] = Jp[3 * r] * vi[0] + Jp[3 * r + 1] * vi[1] + Jp[3 * r + 2] * vi[2];
+                    T[3 * r + 1] = Jp[3 * r] * vi[1] + Jp[3 * r + 1] * vi[3] + Jp[3 * r + 2] * vi[4];
+                    T[3 * r + 2] = Jp[3 * r] * vi[2] + Jp[3 * r + 1] * vi[4] + Jp[3 * r + 2] * vi[5];
+                }
+                n00 -= T[0] * Jp[0] + T[1] * Jp[1] + T[2] * Jp[2];
+                n01 -= T[0] * Jp[3] + T[1] * Jp[4] + T[2] * Jp[5];
+                n11 -= T[3] * Jp[3] + T[4] * Jp[4] + T[5] * Jp[5];
+                e0 += T[0] * g[0] + T[1] * g[1] + T[2] * g[2];
+                e1 += T[3] * g[0] + T[4] * g[1] + T[5] * g[2];
+            }
+            // Jc row 0 is structurally zero at column 2, row 1 at column 0 (see camera_jac)
+            real B0[6], B1[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                B0[q] = q == 2 ? n01 * Jc[8] : (q == 0 ? n00 * Jc[0] : fma(n00, Jc[q], n01 * Jc[6 + q]));
+                B1[q] = q == 2 ? n11 * Jc[8] : (q == 0 ? n01 * Jc[0] : fma(n01, Jc[q], n11 * Jc[6 + q]));
+            }
+            int idx = 0;
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+#pragma unroll
+                for (int q = p; q < 6; q++) {
+                    real t = acc[idx];
+                    if (p != 0) t = fma(Jc[6 + p], B1[q], t);
+                    if (p != 2) t = fma(Jc[p], B0[q], t);
+                    acc[idx++] = t;
+                }
+                real t1 = acc[21 + p], t2 = acc[27 + p], t3 = acc[33 + p];
+                if (p != 0) { t1 = fma(Jc[6 + p], e1, t1); t2 = fma(Jc[6 + p], Jc[6 + p], t2); t3 = fma(Jc[6 + p], o.r1, t3); }
+                if (p != 2) { t1 = fma(Jc[p], e0, t1); t2 = fma(Jc[p], Jc[p], t2); t3 = fma(Jc[p], o.r0, t3); }
+                acc[21 + p] = t1; acc[27 + p] = t2; acc[33 + p] = t3;
+            }
+            k = kn; have = hn; j = jn; u = un; vv = vn;
+#pragma unroll
+            for (int m = 0; m < kRec; m++) rec[m] = recn[m];
+        }
+        const real s1 = group_reduce<21, WAVES>(acc, lds_wave, xw, lane, wave);
+        const real s2 = group_reduce<18, WAVES>(acc + 21, lds_wave, xw, lane, wave);
+        if (wave == 0) {
+            if (it.single) {
+                if (lane < 21) store_diag_value(rv, it.blk, lane, s1);
+                if (lane < 18) store_diag_value(rv, it.blk, 21 + lane, s2);
+            } else {
+                if (lane < 21) diag_partial[(int64_t)item * kDiagVals + lane] = s1;
+                if (lane < 18) diag_partial[(int64_t)item * kDiagVals + 21 + lane] = s2;
+            }
+        }
+    } else {
+        real acc[kOffVals];
+#pragma unroll
+        for (int v = 0; v < kOffVals; v++) acc[v] = real(0);
         CamData A, B;
-        load_cam(cams, ca, A);
-        load_cam(cams, cb, B);
-        for (int k = b + lane; k < e; k += kWave) {
-            const int j = bent[k];
-            const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
-            real vi[6];
-#pragma unroll
-            for (int m = 0; m < 6; m++) vi[m] = Vinv6[6 * j + m];
+        load_cam(cams, it.ca, A);
+        load_cam(cams, it.cb, B);
+        int k = it.begin + (int)threadIdx.x;
+        bool have = k < it.end;
+        real rec[10];
+        int j = 0;
+        if (have) { j = bent[k]; load_rec(lmrec, j, rec, 5); }
+        while (have) {
+            const int kn = k + kStride;
+            const bool hn = kn < it.end;
+            real recn[10];
+            int jn = 0;
+            if (hn) { jn = bent[kn]; load_rec(lmrec, jn, recn, 5); }
+            const real *P = rec, *vi = rec + 3;
             ObsLin oa, ob;
-            // W does not depend on (u,v): pass zeros; only the Huber-weighted edge rescales.
+            // the Jacobians do not depend on (u,v): pass zeros; only the Huber edge rescales
             project_obs(A, P, real(0), real(0), K, oa);
             project_obs(B, P, real(0), real(0), K, ob);
             if (j == hub.pt) {
-                if (ca == hub.cam) scale_lin(oa, *hub_w);
-                if (cb == hub.cam) scale_lin(ob, *hub_w);
+                if (it.ca == hub.cam) scale_lin(oa, *hub_w);
+                if (it.cb == hub.cam) scale_lin(ob, *hub_w);
             }
-            real Jc[12], Jp[6], Wa[18], Wb[18], Z[18];
-            camera_jac(A, oa, P, Jc);
-            point_jac(A, oa, Jp);
-            w_block(Jc, Jp, Wa);
-            camera_jac(B, ob, P, Jc);
-            point_jac(B, ob, Jp);
-            w_block(Jc, Jp, Wb);
-            z_block(Wa, vi, Z);
+            real Jca[12], Jcb[12], Jpa[6], Jpb[6], T[6];
+            camera_jac(A, oa, P, Jca);
+            point_jac(A, oa, Jpa);
+            camera_jac(B, ob, P, Jcb);
+            point_jac(B, ob, Jpb);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                T[3 * r] = Jpa[3 * r] * vi[0] + Jpa[3 * r + 1] * vi[1] + Jpa[3 * r + 2] * vi[2];
+                T[3 * r + 1] = Jpa[3 * r] * vi[1] + Jpa[3 * r + 1] * vi[3] + Jpa[3 * r + 2] * vi[4];
+                T[3 * r + 2] = Jpa[3 * r] * vi[2] + Jpa[3 * r + 1] * vi[4] + Jpa[3 * r + 2] * vi[5];
+            }
+            // M = -(Jp_a Vinv Jp_b^T), so the block update is a pure accumulation
+            const real m00 = -(T[0] * Jpb[0] + T[1] * Jpb[1] + T[2] * Jpb[2]);
+            const real m01 = -(T[0] * Jpb[3] + T[1] * Jpb[4] + T[2] * Jpb[5]);
+            const real m10 = -(T[3] * Jpb[0] + T[4] * Jpb[1] + T[5] * Jpb[2]);
+            const real m11 = -(T[3] * Jpb[3] + T[4] * Jpb[4] + T[5] * Jpb[5]);
+            // Jc row 0 is structurally zero at column 2, row 1 at column 0 (see camera_jac)
+            real B0[6], B1[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                B0[q] = q == 2 ? m01 * Jcb[8] : (q == 0 ? m00 * Jcb[0] : fma(m00, Jcb[q], m01 * Jcb[6 + q]));
+                B1[q] = q == 2 ? m11 * Jcb[8] : (q == 0 ? m10 * Jcb[0] : fma(m10, Jcb[q], m11 * Jcb[6 + q]));
+            }
 #pragma unroll
             for (int p = 0; p < 6; p++)
 #pragma unroll
-                for (int q = 0; q < 6; q++)
-                    acc[6 * p + q] -= Z[3 * p] * Wb[3 * q] + Z[3 * p + 1] * Wb[3 * q + 1] +
-                                      Z[3 * p + 2] * Wb[3 * q + 2];
+                for (int q = 0; q < 6; q++) {
+                    real t = acc[6 * p + q];
+                    if (p != 0) t = fma(Jca[6 + p], B1[q], t);
+                    if (p != 2) t = fma(Jca[p], B0[q], t);
+                    acc[6 * p + q] = t;
+                }
+            k = kn; have = hn; j = jn;
+#pragma unroll
+            for (int m = 0; m < 10; m++) rec[m] = recn[m];
         }
-    }
-    real *lds_wave = red + wave * 18 * kRedStride;
-    const real s1 = wave_reduce_transposed<18>(acc, lds_wave, lane);
-    const real s2 = wave_reduce_transposed<18>(acc + 18, lds_wave, lane);
-    if (item < n_items && lane < 18) {
-        partial[(int64_t)item * kOffVals + lane] = s1;
-        partial[(int64_t)item * kOffVals + 18 + lane] = s2;
+        const real s1 = group_reduce<18, WAVES>(acc, lds_wave, xw, lane, wave);
+        const real s2 = group_reduce<18, WAVES>(acc + 18, lds_wave, xw, lane, wave);
+        if (wave == 0 && lane < 18) {
+            real *dst = it.single ? rv.S_off + (int64_t)it.blk * 36
+                                  : off_partial + (int64_t)(item - n_diag_items) * kOffVals;
+            dst[lane] = s1;
+            dst[18 + lane] = s2;
+        }
     }
 }
 
-// Fixed-order sum of the per-item partials into the reduce buffer
-//   [ S_diag Nc x 36 | S_off nb_off x 36 | rhs 6Nc | diag(U) 6Nc | g_c 6Nc | cost ].
-// nb_off fixes the buffer layout; only the first nb_sum off-diagonal blocks are summed (0 when
-// points are fixed).  Diagonal damping is NOT applied here (it is added after the cross-GPU sum).
-__global__ void finalize_kernel(int Nc, int nb_off, int nb_sum,
-                                const int *__restrict__ diag_item_ptr,
-                                const real *__restrict__ diag_partial,
-                                const int *__restrict__ off_item_ptr,
-                                const real *__restrict__ off_partial, int n_cost_partials,
-                                const real *__restrict__ cost_partial, real *__restrict__ red)
+// Fixed-order sum of the per-item partials of multi-item blocks into the reduce buffer, and of
+// the landmark kernel's cost partials.  nb_off fixes the buffer layout; only the first nb_sum
+// off-diagonal blocks are touched (0 when points are fixed).  Diagonal damping is NOT applied
+// here (it is added after the cross-GPU sum).
+__global__ void __launch_bounds__(256)
+finalize_kernel(int Nc, int nb_off, int nb_sum, const int *__restrict__ diag_item_ptr,
+                const real *__restrict__ diag_partial, const int *__restrict__ off_item_ptr,
+                const real *__restrict__ off_partial, int n_cost_partials,
+                const real *__restrict__ cost_partial, real *__restrict__ red)
 {
+    __shared__ real scratch[4];
+    const RedView rv = red_view(red, Nc, nb_off);
+    if (blockIdx.x == gridDim.x - 1) {                 // last workgroup: cost
+        real s = real(0);
+        for (int i = threadIdx.x; i < n_cost_partials; i += 256) s += cost_partial[i];
+        s = block_sum_256(s, scratch);
+        if (threadIdx.x == 0) *rv.cost = s;
+        return;
+    }
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    real *S_diag = red;
-    real *S_off = S_diag + (int64_t)Nc * 36;
-    real *rhs = S_off + (int64_t)nb_off * 36;
-    real *udiag = rhs + 6 * (int64_t)Nc;
-    real *gc = udiag + 6 * (int64_t)Nc;
-    real *cost = gc + 6 * (int64_t)Nc;
     const int64_t n_diag = (int64_t)Nc * kDiagVals;
     if (tid < n_diag) {
         const int c = (int)(tid / kDiagVals), v = (int)(tid % kDiagVals);
+        const int i0 = diag_item_ptr[c], i1 = diag_item_ptr[c + 1];
+        if (i1 - i0 == 1) return;                      // written by blocks_kernel
         real s = real(0);
-        for (int it = diag_item_ptr[c]; it < diag_item_ptr[c + 1]; it++)
-            s += diag_partial[(int64_t)it * kDiagVals + v];
-        if (v < 21) {
-            int p = 0, rem = v;
-            while (rem >= 6 - p) { rem -= 6 - p; p++; }
-            const int q = p + rem;
-            S_diag[(int64_t)c * 36 + 6 * p + q] = s;
-            S_diag[(int64_t)c * 36 + 6 * q + p] = s;
-        } else if (v < 27) rhs[6 * c + v - 21] = s;
-        else if (v < 33) udiag[6 * c + v - 27] = s;
-        else gc[6 * c + v - 33] = s;
+        for (int it = i0; it < i1; it++) s += diag_partial[(int64_t)it * kDiagVals + v];
+        store_diag_value(rv, c, v, s);
     } else if (tid < n_diag + (int64_t)nb_sum * kOffVals) {
         const int64_t u = tid - n_diag;
         const int blk = (int)(u / kOffVals), v = (int)(u % kOffVals);
+        const int i0 = off_item_ptr[blk], i1 = off_item_ptr[blk + 1];
+        if (i1 - i0 == 1) return;
         real s = real(0);
-        for (int it = off_item_ptr[blk]; it < off_item_ptr[blk + 1]; it++)
-            s += off_partial[(int64_t)it * kOffVals + v];
-        S_off[(int64_t)blk * 36 + v] = s;
-    } else if (tid == n_diag + (int64_t)nb_sum * kOffVals) {
-        real s = real(0);
-        for (int i = 0; i < n_cost_partials; i++) s += cost_partial[i];
-        *cost = s;
+        for (int it = i0; it < i1; it++) s += off_partial[(int64_t)it * kOffVals + v];
+        rv.S_off[(int64_t)blk * 36 + v] = s;
     }
 }
 
@@ -607,9 +730,9 @@ __global__ void __launch_bounds__(kLmThreads)
 backsub_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                const real *__restrict__ pts, const int *__restrict__ pt_ptr,
                const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
-               const real *__restrict__ hub_w, int fix_points, const real *__restrict__ Vinv6,
-               const real *__restrict__ gp, const real *__restrict__ dcam,
-               real *__restrict__ dpt, real *__restrict__ mcc_partial)
+               const real *__restrict__ hub_w, int fix_points, const real *__restrict__ lmrec,
+               const real *__restrict__ dcam, real *__restrict__ dpt,
+               real *__restrict__ mcc_partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     CamData *scams = reinterpret_cast<CamData *>(smem_raw);
@@ -627,7 +750,8 @@ backsub_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
         const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
         real dp[3] = { 0, 0, 0 };
         if (!fix_points && e > b) {
-            real acc[3] = { gp[3 * j], gp[3 * j + 1], gp[3 * j + 2] };
+            const real *gpj = lmrec + (int64_t)kRec * j + 9;
+            real acc[3] = { gpj[0], gpj[1], gpj[2] };
             for (int pos = b; pos < e; pos++) {
                 const int c = lcam[pos];
                 CamData cd;
@@ -647,7 +771,7 @@ backsub_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
 #pragma unroll
                 for (int k = 0; k < 3; k++) acc[k] += Jp[k] * m0 + Jp[3 + k] * m1;
             }
-            const real *vi = Vinv6 + 6 * (int64_t)j;
+            const real *vi = lmrec + (int64_t)kRec * j + 3;
             dp[0] = -(vi[0] * acc[0] + vi[1] * acc[1] + vi[2] * acc[2]);
             dp[1] = -(vi[1] * acc[0] + vi[3] * acc[1] + vi[4] * acc[2]);
             dp[2] = -(vi[2] * acc[0] + vi[4] * acc[1] + vi[5] * acc[2]);
@@ -717,12 +841,12 @@ candidate_kernel(int Nc, int Np, int fix_points, const real *__restrict__ t,
 // max |g| over camera gradient (6Nc) and, unless fix_points, the landmark gradients (3Np).
 __global__ void __launch_bounds__(256)
 gradient_max_kernel(int64_t nc6, const real *__restrict__ gc, int64_t np3,
-                    const real *__restrict__ gp, real *__restrict__ out)
+                    const real *__restrict__ lmrec, real *__restrict__ out)
 {
     __shared__ real red[4];
     real m = 0;
     for (int64_t i = threadIdx.x; i < nc6; i += 256) m = fmax(m, fabs(gc[i]));
-    for (int64_t i = threadIdx.x; i < np3; i += 256) m = fmax(m, fabs(gp[i]));
+    for (int64_t i = threadIdx.x; i < np3; i += 256) m = fmax(m, fabs(lmrec[(i / 3) * kRec + 9 + i % 3]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;

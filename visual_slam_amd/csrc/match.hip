@@ -120,30 +120,35 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    // staging map: 128 rows x 4 chunks of 16 B per operand tile; 2 chunks per thread
-    uint4 st[8];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int c = tid + 256 * s, row = c >> 2, ch = c & 3;
-            const int64_t off = (int64_t)row * kD + kt * kBK + ch * 8;
-            st[s] = *reinterpret_cast<const uint4 *>(gA_hi + off);
-            st[2 + s] = *reinterpret_cast<const uint4 *>(gA_lo + off);
-            st[4 + s] = *reinterpret_cast<const uint4 *>(gB_hi + off);
-            st[6 + s] = *reinterpret_cast<const uint4 *>(gB_lo + off);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int c = tid + 256 * s, row = c >> 2, ch = c & 3;
-            const int off = row * kRowH + ch * 8;
-            *reinterpret_cast<uint4 *>(sA_hi + off) = st[s];
-            *reinterpret_cast<uint4 *>(sA_lo + off) = st[2 + s];
-            *reinterpret_cast<uint4 *>(sB_hi + off) = st[4 + s];
-            *reinterpret_cast<uint4 *>(sB_lo + off) = st[6 + s];
-        }
-    };
+    // staging map: 128 rows x 4 chunks of 16 B per operand tile; 2 chunks per thread, held in
+    // named registers (an indexed array would be demoted to scratch memory)
+    const int c0 = tid, c1 = tid + 256;
+    const int64_t g0 = (int64_t)(c0 >> 2) * kD + (c0 & 3) * 8, g1 = (int64_t)(c1 >> 2) * kD + (c1 & 3) * 8;
+    const int l0 = (c0 >> 2) * kRowH + (c0 & 3) * 8, l1 = (c1 >> 2) * kRowH + (c1 & 3) * 8;
+    uint4 ra0, ra1, rb0, rb1, rc0, rc1, rd0, rd1;
+#define VS_LOAD_TILE(kt)                                                                   \
+    do {                                                                                   \
+        const int ko = (kt) * kBK;                                                         \
+        ra0 = *reinterpret_cast<const uint4 *>(gA_hi + g0 + ko);                           \
+        ra1 = *reinterpret_cast<const uint4 *>(gA_hi + g1 + ko);                           \
+        rb0 = *reinterpret_cast<const uint4 *>(gA_lo + g0 + ko);                           \
+        rb1 = *reinterpret_cast<const uint4 *>(gA_lo + g1 + ko);                           \
+        rc0 = *reinterpret_cast<const uint4 *>(gB_hi + g0 + ko);                           \
+        rc1 = *reinterpret_cast<const uint4 *>(gB_hi + g1 + ko);                           \
+        rd0 = *reinterpret_cast<const uint4 *>(gB_lo + g0 + ko);                           \
+        rd1 = *reinterpret_cast<const uint4 *>(gB_lo + g1 + ko);                           \
+    } while (0)
+#define VS_STORE_TILE()                                                                    \
+    do {                                                                                   \
+        *reinterpret_cast<uint4 *>(sA_hi + l0) = ra0;                                      \
+        *reinterpret_cast<uint4 *>(sA_hi + l1) = ra1;                                      \
+        *reinterpret_cast<uint4 *>(sA_lo + l0) = rb0;                                      \
+        *reinterpret_cast<uint4 *>(sA_lo + l1) = rb1;                                      \
+        *reinterpret_cast<uint4 *>(sB_hi + l0) = rc0;                                      \
+        *reinterpret_cast<uint4 *>(sB_hi + l1) = rc1;                                      \
+        *reinterpret_cast<uint4 *>(sB_lo + l0) = rd0;                                      \
+        *reinterpret_cast<uint4 *>(sB_lo + l1) = rd1;                                      \
+    } while (0)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -153,13 +158,13 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-    load_tile(0);
+    VS_LOAD_TILE(0);
     constexpr int kSteps = kD / kBK;
     for (int kt = 0; kt < kSteps; kt++) {
         __syncthreads();
-        store_tile();
+        VS_STORE_TILE();
         __syncthreads();
-        if (kt + 1 < kSteps) load_tile(kt + 1);
+        if (kt + 1 < kSteps) VS_LOAD_TILE(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < kBK / 16; ks++) {
             // fragment of a 32x32x16 MFMA: lane holds 8 consecutive k of row/col (lane & 31),
@@ -189,6 +194,8 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
         }
     }
 
+#undef VS_LOAD_TILE
+#undef VS_STORE_TILE
     // ---- epilogue --------------------------------------------------------------------------
     // element (m, n, r) of this lane: row gi = i0 + wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
     //                                 col gj = j0 + wc*64 + n*32 + (lane&31)

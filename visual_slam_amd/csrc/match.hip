@@ -103,12 +103,23 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
 
     const int pair = blockIdx.z;
     const int ntc = n1_pad / kBN, ntr = n0_pad / kBM;
-    // XCD-aware tile order: workgroups that land on one XCD (blockIdx.x % 8) walk a contiguous
-    // range of tile rows, so the A rows they share stay in that XCD's L2.
-    int lin = blockIdx.x;
-    const int T = ntr * ntc;
-    if ((T & 7) == 0) lin = (lin & 7) * (T >> 3) + (lin >> 3);
-    const int tile_r = lin / ntc, tile_c = lin % ntc;
+    (void)ntc;
+    // XCD-aware tile order: workgroups that land on one XCD (blockIdx.x % 8) take a band of
+    // `rpx` tile rows and walk it column by column, so the band's A rows stay in that XCD's L2
+    // and each B panel is fetched once per band instead of once per tile row.
+    int tile_r, tile_c;
+    {
+        const int lin = blockIdx.x;
+        if ((ntr & 7) == 0) {
+            const int rpx = ntr >> 3;                  // tile rows per XCD
+            const int q = lin >> 3;                    // position inside the XCD's band
+            tile_r = (lin & 7) * rpx + q % rpx;
+            tile_c = q / rpx;
+        } else {
+            tile_r = lin / ntc;
+            tile_c = lin % ntc;
+        }
+    }
     const int n0 = dims[pair].n0, n1 = dims[pair].n1;
     const int i0 = tile_r * kBM, j0 = tile_c * kBN;
     if (i0 >= n0 || j0 >= n1) return;   // tile fully outside this pair: nothing reads its partials
@@ -269,7 +280,7 @@ __global__ void __launch_bounds__(256)
 merge_kernel(const PairDims *__restrict__ dims, int n_pad_items, int n_parts,
              int dir, const float *__restrict__ b1, const int *__restrict__ i1,
              const float *__restrict__ b2, int *__restrict__ nn_idx,
-             unsigned char *__restrict__ uncertain, int force_uncertain)
+             unsigned char *__restrict__ uncertain, float *__restrict__ best, int force_uncertain)
 {
     const int pair = blockIdx.y;
     const int it = blockIdx.x * 256 + threadIdx.x;
@@ -283,6 +294,7 @@ merge_kernel(const PairDims *__restrict__ dims, int n_pad_items, int n_parts,
         top2_merge(t, b1[o], i1[o], b2[o]);
     }
     nn_idx[(int64_t)pair * n_pad_items + it] = t.i1;
+    best[(int64_t)pair * n_pad_items + it] = t.b1;
     uncertain[(int64_t)pair * n_pad_items + it] = (force_uncertain || !(t.b1 - t.b2 > kBand)) ? 1 : 0;
 }
 
@@ -313,46 +325,211 @@ __device__ __forceinline__ bool stereo_masked(int2 p0, int2 p1)
     return dy > 20 || p0.x < p1.x;
 }
 
-// Certain items: exact distance of the winner.  Uncertain items: appended to the rescan list.
-// One thread per item over both directions: item < n0_pad -> row, else column.
+constexpr int kPanel = 32;               // floats of each row staged per step
+constexpr int kPanelStride = 36;         // LDS row stride in floats (conflict-free ds_read_b128)
+
+// Cooperative exact dots: each of the 64 lanes owns one (row of desc0, row of desc1) pair whose
+// base pointers sit in pA/pB (LDS).  Rows are staged panel by panel with coalesced 128-byte
+// segments (the next panel is already in flight while the current one is consumed), then every
+// lane accumulates ITS OWN pair in index order (fp64 fma of exact products = the reference's
+// double accumulation).  UNIFORM_A: every lane's first row is pA[0]; it is staged once, whole,
+// into tA (256 floats).
+template <bool UNIFORM_A>
+__device__ __forceinline__ double panel_dot64(const float *const *pA, const float *const *pB,
+                                              float *tA, float *tB, int lane)
+{
+    double acc = 0.0;
+    const int seg = lane & 7, sub = lane >> 3;
+    if (UNIFORM_A)
+        *reinterpret_cast<float4 *>(tA + lane * 4) = *reinterpret_cast<const float4 *>(pA[0] + lane * 4);
+    float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7;
+#define VS_PANEL_LOAD(po)                                                                        \
+    do {                                                                                         \
+        const int o_ = (po) + seg * 4;                                                           \
+        rb0 = *reinterpret_cast<const float4 *>(pB[sub] + o_);                                   \
+        rb1 = *reinterpret_cast<const float4 *>(pB[8 + sub] + o_);                               \
+        rb2 = *reinterpret_cast<const float4 *>(pB[16 + sub] + o_);                              \
+        rb3 = *reinterpret_cast<const float4 *>(pB[24 + sub] + o_);                              \
+        rb4 = *reinterpret_cast<const float4 *>(pB[32 + sub] + o_);                              \
+        rb5 = *reinterpret_cast<const float4 *>(pB[40 + sub] + o_);                              \
+        rb6 = *reinterpret_cast<const float4 *>(pB[48 + sub] + o_);                              \
+        rb7 = *reinterpret_cast<const float4 *>(pB[56 + sub] + o_);                              \
+        if (!UNIFORM_A) {                                                                        \
+            ra0 = *reinterpret_cast<const float4 *>(pA[sub] + o_);                               \
+            ra1 = *reinterpret_cast<const float4 *>(pA[8 + sub] + o_);                           \
+            ra2 = *reinterpret_cast<const float4 *>(pA[16 + sub] + o_);                          \
+            ra3 = *reinterpret_cast<const float4 *>(pA[24 + sub] + o_);                          \
+            ra4 = *reinterpret_cast<const float4 *>(pA[32 + sub] + o_);                          \
+            ra5 = *reinterpret_cast<const float4 *>(pA[40 + sub] + o_);                          \
+            ra6 = *reinterpret_cast<const float4 *>(pA[48 + sub] + o_);                          \
+            ra7 = *reinterpret_cast<const float4 *>(pA[56 + sub] + o_);                          \
+        }                                                                                        \
+    } while (0)
+#define VS_PANEL_PUT(t, g, r) *reinterpret_cast<float4 *>((t) + ((g)*8 + sub) * kPanelStride + seg * 4) = (r)
+    VS_PANEL_LOAD(0);
+#pragma unroll 1
+    for (int p = 0; p < kD / kPanel; p++) {
+        VS_PANEL_PUT(tB, 0, rb0); VS_PANEL_PUT(tB, 1, rb1); VS_PANEL_PUT(tB, 2, rb2); VS_PANEL_PUT(tB, 3, rb3);
+        VS_PANEL_PUT(tB, 4, rb4); VS_PANEL_PUT(tB, 5, rb5); VS_PANEL_PUT(tB, 6, rb6); VS_PANEL_PUT(tB, 7, rb7);
+        if (!UNIFORM_A) {
+            VS_PANEL_PUT(tA, 0, ra0); VS_PANEL_PUT(tA, 1, ra1); VS_PANEL_PUT(tA, 2, ra2); VS_PANEL_PUT(tA, 3, ra3);
+            VS_PANEL_PUT(tA, 4, ra4); VS_PANEL_PUT(tA, 5, ra5); VS_PANEL_PUT(tA, 6, ra6); VS_PANEL_PUT(tA, 7, ra7);
+        }
+        __syncthreads();
+        if (p + 1 < kD / kPanel) VS_PANEL_LOAD((p + 1) * kPanel);
+#pragma unroll
+        for (int q = 0; q < kPanel / 4; q++) {
+            const float4 y = *reinterpret_cast<const float4 *>(tB + lane * kPanelStride + q * 4);
+            float4 x;
+            if (UNIFORM_A) x = *reinterpret_cast<const float4 *>(tA + p * kPanel + q * 4);
+            else x = *reinterpret_cast<const float4 *>(tA + lane * kPanelStride + q * 4);
+            acc = fma((double)x.x, (double)y.x, acc);
+            acc = fma((double)x.y, (double)y.y, acc);
+            acc = fma((double)x.z, (double)y.z, acc);
+            acc = fma((double)x.w, (double)y.w, acc);
+        }
+        __syncthreads();
+    }
+#undef VS_PANEL_LOAD
+#undef VS_PANEL_PUT
+    return acc;
+}
+
+__device__ __forceinline__ float distance_from_dot(double acc)
+{
+    float s = (float)acc;
+    s = (s < -1.0f) ? -1.0f : (1.0f < s) ? 1.0f : s;
+    return sqrtf(2.0f - 2.0f * s);
+}
+
+// Certain items: exact distance of the winner.  Uncertain items: appended to the rescan list and
+// their packed (distance, index) key reset.  One wave per 64 items over both directions:
+// item < n0_pad -> row, else column.
 template <bool MASKED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 exact_winner_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
                     const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
                     const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
                     const int *__restrict__ idx0, const int *__restrict__ idx1,
                     const unsigned char *__restrict__ unc0, const unsigned char *__restrict__ unc1,
                     float *__restrict__ dist0, float *__restrict__ dist1,
-                    int *__restrict__ rescan_list, int *__restrict__ rescan_count)
+                    int *__restrict__ rescan_list, int *__restrict__ rescan_count,
+                    unsigned long long *__restrict__ keys)
 {
+    __shared__ __attribute__((aligned(16))) float tA[64 * kPanelStride];
+    __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
+    __shared__ const float *pA[64];
+    __shared__ const float *pB[64];
     const int pair = blockIdx.y;
-    const int it = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int it = blockIdx.x * 64 + lane;
     const int n0 = dims[pair].n0, n1 = dims[pair].n1;
-    int i, j;
-    bool unc;
+    int i = 0, j = 0;
+    bool valid = false, unc = false;
     if (it < n0_pad) {
-        if (it >= n0) return;
-        i = it; j = idx0[(int64_t)pair * n0_pad + it]; unc = unc0[(int64_t)pair * n0_pad + it];
-    } else {
+        if (it < n0) { valid = true; i = it; j = idx0[(int64_t)pair * n0_pad + it]; unc = unc0[(int64_t)pair * n0_pad + it]; }
+    } else if (it - n0_pad < n1) {
         const int c = it - n0_pad;
-        if (c >= n1) return;
-        j = c; i = idx1[(int64_t)pair * n1_pad + c]; unc = unc1[(int64_t)pair * n1_pad + c];
+        valid = true; j = c; i = idx1[(int64_t)pair * n1_pad + c]; unc = unc1[(int64_t)pair * n1_pad + c];
     }
+    bool masked = false;
+    if (MASKED && valid && !unc)
+        masked = stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j]);
+    pA[lane] = d0 + ((int64_t)pair * n0_pad + i) * kD;
+    pB[lane] = d1 + ((int64_t)pair * n1_pad + j) * kD;
+    __syncthreads();
+    const double acc = panel_dot64<false>(pA, pB, tA, tB, lane);
+    if (!valid) return;
     if (unc) {
         const int slot = atomicAdd(rescan_count, 1);
         rescan_list[2 * (int64_t)slot] = pair;
         rescan_list[2 * (int64_t)slot + 1] = it;
+        keys[(int64_t)pair * (n0_pad + n1_pad) + it] = ~0ull;
         return;
     }
-    float d;
-    if (MASKED && stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j])) d = 1.0f;
-    else d = exact_distance(d0 + ((int64_t)pair * n0_pad + i) * kD, d1 + ((int64_t)pair * n1_pad + j) * kD);
+    const float d = masked ? 1.0f : distance_from_dot(acc);
     if (it < n0_pad) dist0[(int64_t)pair * n0_pad + it] = d;
     else dist1[(int64_t)pair * n1_pad + it - n0_pad] = d;
 }
 
-// Exact scan of one whole row or column per wave (first minimum), for the listed items.
-// Also yields the exact second-smallest distance of rows (for the optional ratio test).
+// Exact re-decision of the listed rows/columns, 64 candidates per wave task: exact distances
+// from staged panels, wave minimum with lowest-index tie-break, one 64-bit atomic min of the
+// packed (distance bits, index) key per task (non-negative floats order like their bit patterns).
+template <bool MASKED>
+__global__ void __launch_bounds__(64)
+rescan_chunk_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+                    const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
+                    const int2 *__restrict__ xy1, int n0_pad, int n1_pad, int chunks,
+                    const int *__restrict__ rescan_list, const int *__restrict__ rescan_count,
+                    const float *__restrict__ row_b1, const float *__restrict__ col_b1,
+                    const float *__restrict__ best0, const float *__restrict__ best1,
+                    unsigned long long *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
+    __shared__ __attribute__((aligned(16))) float tA[kD];
+    __shared__ const float *pA[1];
+    __shared__ const float *pB[64];
+    const int lane = threadIdx.x;
+    const int64_t n_tasks = (int64_t)(*rescan_count) * chunks;
+    for (int64_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
+        const int w = (int)(t / chunks), chunk = (int)(t % chunks);
+        const int pair = rescan_list[2 * (int64_t)w], it = rescan_list[2 * (int64_t)w + 1];
+        const int n0 = dims[pair].n0, n1 = dims[pair].n1;
+        const bool is_row = it < n0_pad;
+        const int self = is_row ? it : it - n0_pad;
+        const int n_cand = is_row ? n1 : n0;
+        if (chunk * 64 >= n_cand) continue;                          // uniform per workgroup
+        // a chunk whose best approximate score is more than the band below the item's best
+        // cannot contain the exact first minimum
+        const float chunk_best = is_row ? row_b1[((int64_t)pair * (n1_pad / kSub) + chunk) * n0_pad + self]
+                                        : col_b1[((int64_t)pair * (n0_pad / kSub) + chunk) * n1_pad + self];
+        const float item_best = is_row ? best0[(int64_t)pair * n0_pad + self] : best1[(int64_t)pair * n1_pad + self];
+        if (!(item_best - chunk_best <= kBand)) continue;
+        const int c = chunk * 64 + lane;
+        __syncthreads();
+        if (lane == 0)
+            pA[0] = is_row ? d0 + ((int64_t)pair * n0_pad + self) * kD : d1 + ((int64_t)pair * n1_pad + self) * kD;
+        pB[lane] = is_row ? d1 + ((int64_t)pair * n1_pad + c) * kD : d0 + ((int64_t)pair * n0_pad + c) * kD;
+        __syncthreads();
+        const double acc = panel_dot64<true>(pA, pB, tA, tB, lane);
+        float d = 3.0e38f;
+        if (c < n_cand) {
+            d = distance_from_dot(acc);
+            if (MASKED) {
+                const int i = is_row ? self : c, j = is_row ? c : self;
+                if (stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j])) d = 1.0f;
+            }
+        }
+        unsigned long long key = c < n_cand ? ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)c : ~0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o < key ? o : key;
+        }
+        if (lane == 0) atomicMin(&keys[(int64_t)pair * (n0_pad + n1_pad) + it], key);
+    }
+}
+
+// Unpack the keys of the re-decided items into the index / distance arrays.
+__global__ void __launch_bounds__(256)
+unpack_kernel(int n0_pad, int n1_pad, const int *__restrict__ rescan_list,
+              const int *__restrict__ rescan_count, const unsigned long long *__restrict__ keys,
+              int *__restrict__ idx0, int *__restrict__ idx1, float *__restrict__ dist0,
+              float *__restrict__ dist1)
+{
+    const int count = *rescan_count;
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+        const int pair = rescan_list[2 * (int64_t)w], it = rescan_list[2 * (int64_t)w + 1];
+        const unsigned long long key = keys[(int64_t)pair * (n0_pad + n1_pad) + it];
+        const int idx = (int)(key & 0xffffffffu);
+        const float d = __uint_as_float((unsigned)(key >> 32));
+        if (it < n0_pad) { idx0[(int64_t)pair * n0_pad + it] = idx; dist0[(int64_t)pair * n0_pad + it] = d; }
+        else { idx1[(int64_t)pair * n1_pad + it - n0_pad] = idx; dist1[(int64_t)pair * n1_pad + it - n0_pad] = d; }
+    }
+}
+
+// Ratio-test mode only: exact scan of one whole row or column per wave (first minimum) that
+// also yields the exact second-smallest distance of rows.
 template <bool MASKED>
 __global__ void __launch_bounds__(256)
 rescan_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
@@ -472,9 +649,10 @@ struct vs_matcher {
     DevBuf<_Float16> a_hi, a_lo, b_hi, b_lo;
     DevBuf<int2> xy0, xy1;
     DevBuf<PairDims> dims;
-    DevBuf<float> row_b1, row_b2, col_b1, col_b2, dist0, dist1, second0, out_d;
+    DevBuf<float> row_b1, row_b2, col_b1, col_b2, dist0, dist1, second0, out_d, best0, best1;
     DevBuf<int> row_i1, col_i1, idx0, idx1, rescan_list, rescan_count, out_i, out_j, out_n;
     DevBuf<unsigned char> unc0, unc1;
+    DevBuf<unsigned long long> keys;
 };
 
 extern "C" {
@@ -503,8 +681,8 @@ int vs_matcher_create(vs_matcher_handle *out, int32_t max_pairs, int32_t max_n0,
     A(m->row_b1.alloc(rp)); A(m->row_b2.alloc(rp)); A(m->row_i1.alloc(rp));
     A(m->col_b1.alloc(cp)); A(m->col_b2.alloc(cp)); A(m->col_i1.alloc(cp));
     A(m->idx0.alloc(P * r0)); A(m->idx1.alloc(P * r1)); A(m->dist0.alloc(P * r0)); A(m->dist1.alloc(P * r1));
-    A(m->second0.alloc(P * r0)); A(m->unc0.alloc(P * r0)); A(m->unc1.alloc(P * r1));
-    A(m->rescan_list.alloc(2 * P * (r0 + r1))); A(m->rescan_count.alloc(4));
+    A(m->second0.alloc(P * r0)); A(m->best0.alloc(P * r0)); A(m->best1.alloc(P * r1)); A(m->unc0.alloc(P * r0)); A(m->unc1.alloc(P * r1));
+    A(m->rescan_list.alloc(2 * P * (r0 + r1))); A(m->rescan_count.alloc(4)); A(m->keys.alloc(P * (r0 + r1)));
     A(m->out_i.alloc(P * r0)); A(m->out_j.alloc(P * r0)); A(m->out_d.alloc(P * r0)); A(m->out_n.alloc(P));
     if (rc != VS_OK) { delete m; return rc; }
     m->h_dims.assign(P, PairDims{ 0, 0 });
@@ -582,27 +760,43 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
     mark(1);
     const int force = ratio < 1.0f ? 1 : 0;   // the ratio test needs every row's exact second best
     hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0, 256), n_pairs), dim3(256), 0, s, m->dims.p, r0, r1 / kSub, 0,
-                       m->row_b1.p, m->row_i1.p, m->row_b2.p, m->idx0.p, m->unc0.p, force);
+                       m->row_b1.p, m->row_i1.p, m->row_b2.p, m->idx0.p, m->unc0.p, m->best0.p, force);
     hipLaunchKernelGGL(merge_kernel, dim3(div_up(r1, 256), n_pairs), dim3(256), 0, s, m->dims.p, r1, r0 / kSub, 1,
-                       m->col_b1.p, m->col_i1.p, m->col_b2.p, m->idx1.p, m->unc1.p, 0);
+                       m->col_b1.p, m->col_i1.p, m->col_b2.p, m->idx1.p, m->unc1.p, m->best1.p, 0);
     VS_TRY(launch_ok("merge_kernel"));
     mark(2);
     VS_HIP(hipMemsetAsync(m->rescan_count.p, 0, 4 * sizeof(int), s));
-    const dim3 egrid(div_up(r0 + r1, 256), n_pairs);
-    if (masked) {
-        hipLaunchKernelGGL(exact_winner_kernel<true>, egrid, dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
+    const dim3 egrid(div_up(r0 + r1, 64), n_pairs);
+    const int chunks = std::max(r0, r1) / 64;
+    if (masked)
+        hipLaunchKernelGGL(exact_winner_kernel<true>, egrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
                            m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->unc0.p, m->unc1.p, m->dist0.p, m->dist1.p,
-                           m->rescan_list.p, m->rescan_count.p);
-        hipLaunchKernelGGL(rescan_kernel<true>, dim3(2048), dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
-                           m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->idx0.p, m->idx1.p,
-                           m->dist0.p, m->dist1.p, m->second0.p);
+                           m->rescan_list.p, m->rescan_count.p, m->keys.p);
+    else
+        hipLaunchKernelGGL(exact_winner_kernel<false>, egrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
+                           m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->unc0.p, m->unc1.p, m->dist0.p, m->dist1.p,
+                           m->rescan_list.p, m->rescan_count.p, m->keys.p);
+    if (force) {
+        // ratio test: every row needs its exact second-best distance -> whole-row scans
+        if (masked)
+            hipLaunchKernelGGL(rescan_kernel<true>, dim3(2048), dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
+                               m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->idx0.p, m->idx1.p,
+                               m->dist0.p, m->dist1.p, m->second0.p);
+        else
+            hipLaunchKernelGGL(rescan_kernel<false>, dim3(2048), dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
+                               m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->idx0.p, m->idx1.p,
+                               m->dist0.p, m->dist1.p, m->second0.p);
     } else {
-        hipLaunchKernelGGL(exact_winner_kernel<false>, egrid, dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
-                           m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->unc0.p, m->unc1.p, m->dist0.p, m->dist1.p,
-                           m->rescan_list.p, m->rescan_count.p);
-        hipLaunchKernelGGL(rescan_kernel<false>, dim3(2048), dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
-                           m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->idx0.p, m->idx1.p,
-                           m->dist0.p, m->dist1.p, m->second0.p);
+        if (masked)
+            hipLaunchKernelGGL(rescan_chunk_kernel<true>, dim3(16384), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
+                               m->xy0.p, m->xy1.p, r0, r1, chunks, m->rescan_list.p, m->rescan_count.p, m->row_b1.p, m->col_b1.p,
+                               m->best0.p, m->best1.p, m->keys.p);
+        else
+            hipLaunchKernelGGL(rescan_chunk_kernel<false>, dim3(16384), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
+                               m->xy0.p, m->xy1.p, r0, r1, chunks, m->rescan_list.p, m->rescan_count.p, m->row_b1.p, m->col_b1.p,
+                               m->best0.p, m->best1.p, m->keys.p);
+        hipLaunchKernelGGL(unpack_kernel, dim3(64), dim3(256), 0, s, r0, r1, m->rescan_list.p, m->rescan_count.p,
+                           m->keys.p, m->idx0.p, m->idx1.p, m->dist0.p, m->dist1.p);
     }
     VS_TRY(launch_ok("exact kernels"));
     mark(3);

@@ -7,7 +7,11 @@ LIB := visual_slam_amd/lib/libvslam_hip.so
 OBJS := $(CSRC)/ba.o $(CSRC)/match.o $(CSRC)/capi.o
 HDRS := include/vslam_hip.h $(wildcard $(CSRC)/*.h)
 
-all: $(LIB) oracle
+HOST := visual_slam_amd/host
+HOSTLIB := visual_slam_amd/lib/libvslam_host.so
+HARNESS := tests/cpp/adapter_harness
+
+all: $(LIB) $(HOSTLIB) $(HARNESS) oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -16,11 +20,18 @@ $(LIB): $(OBJS)
 	@mkdir -p visual_slam_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# C++ host adapters keeping the reference's class interfaces, above the C ABI
+$(HOSTLIB): $(HOST)/optimizer.cc $(HOST)/superpoint_matcher.cc $(HOST)/*.h include/vslam_hip.h $(LIB)
+	g++ -O2 -std=c++14 -fPIC -shared -Wall -Iinclude -I$(HOST) -o $@ $(HOST)/optimizer.cc $(HOST)/superpoint_matcher.cc -Lvisual_slam_amd/lib -lvslam_hip -Wl,-rpath,'$$ORIGIN'
+
+$(HARNESS): tests/cpp/adapter_harness.cc $(HOSTLIB)
+	g++ -O2 -std=c++14 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/adapter_harness.cc -Lvisual_slam_amd/lib -lvslam_host -lvslam_hip -Wl,-rpath,'$$ORIGIN/../../visual_slam_amd/lib'
+
 oracle:
 	$(MAKE) -s -C oracle
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(HOSTLIB) $(HARNESS)
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,103 @@
+// Test harness for the C++ host adapters: replays the reference's call order
+// (Tracking::solveCamera / solvePoints, src/core/tracking.cc:79-163) on a problem read from a
+// binary file written by the pytest side, and writes the results back.
+//   adapter_harness <in.bin> <out.bin>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <list>
+#include <vector>
+
+#include "optimizer.h"
+#include "superpoint_matcher.h"
+
+using namespace visual_slam;
+
+template <typename T>
+static std::vector<T> rd(FILE *f, size_t n)
+{
+    std::vector<T> v(n);
+    if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+    return v;
+}
+
+template <typename T>
+static void wr(FILE *f, const T *p, size_t n)
+{
+    if (n && fwrite(p, sizeof(T), n, f) != n) { fprintf(stderr, "short write\n"); exit(2); }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) return 1;
+    FILE *fi = fopen(argv[1], "rb"), *fo = fopen(argv[2], "wb");
+    if (!fi || !fo) return 1;
+    const int mode = rd<int32_t>(fi, 1)[0];
+    if (mode == 0) {
+        auto hdr = rd<int32_t>(fi, 3);
+        const int nf = hdr[0], np = hdr[1], fix = hdr[2];
+        auto poses = rd<float>(fi, (size_t)nf * 7);
+        std::vector<std::vector<Point2i>> keys(nf);
+        for (int f = 0; f < nf; f++) {
+            const int nk = rd<int32_t>(fi, 1)[0];
+            auto k = rd<int32_t>(fi, (size_t)nk * 2);
+            for (int i = 0; i < nk; i++) keys[f].push_back(Point2i{ k[2 * i], k[2 * i + 1] });
+        }
+        auto tr = rd<int32_t>(fi, (size_t)nf * np);
+        auto pw = rd<float>(fi, (size_t)np * 3);
+        std::list<std::vector<int>> tracks;
+        for (int f = 0; f < nf; f++) tracks.emplace_back(tr.begin() + (size_t)f * np, tr.begin() + (size_t)(f + 1) * np);
+        std::vector<core::TrackedPoint> tps(np);
+        std::vector<core::TrackedPoint *> tpp;
+        for (int j = 0; j < np; j++) { tps[j].Pw = { { pw[3 * j], pw[3 * j + 1], pw[3 * j + 2] } }; tpp.push_back(&tps[j]); }
+        // tracking.cc:81-99
+        core::Optimizer opt;
+        for (int f = 0; f < nf; f++) {
+            transform::Rigid3f p;
+            p.translation = { { poses[7 * f], poses[7 * f + 1], poses[7 * f + 2] } };
+            p.rotation = { { poses[7 * f + 3], poses[7 * f + 4], poses[7 * f + 5], poses[7 * f + 6] } };
+            opt.addPose(p);
+            opt.addKeys(keys[f]);
+        }
+        opt.addPoints(tpp);
+        core::Problem problem;
+        Matrix3f K = { { 170.5f, 0.f, 191.5f, 0.f, 170.5f, 103.4f, 0.f, 0.f, 1.f } };   // tracking.cc:58-62
+        opt.addReprojectionEdges(problem, K, tracks, fix != 0);
+        if (problem.status != VS_OK) { fprintf(stderr, "edges: %s\n", problem.error.c_str()); return 3; }
+        if (!opt.solve()) { fprintf(stderr, "solve: %s\n", problem.error.c_str()); return 3; }
+        // tracking.cc:113-118
+        std::vector<float> out((size_t)nf * 7);
+        for (int f = 0; f < nf; f++) {
+            const auto p = opt.getPose(f);
+            for (int k = 0; k < 3; k++) out[7 * f + k] = p.translation[k];
+            for (int k = 0; k < 4; k++) out[7 * f + 3 + k] = p.rotation[k];
+        }
+        wr(fo, out.data(), out.size());
+        auto &pts = opt.getPoints();
+        for (auto &p : pts) wr(fo, p.data(), 3);
+        const int32_t it = opt.summary().iterations;
+        const double fc = opt.summary().final_cost;
+        wr(fo, &it, 1);
+        wr(fo, &fc, 1);
+    } else {
+        auto hdr = rd<int32_t>(fi, 2);
+        const int n0 = hdr[0], n1 = hdr[1];
+        auto d0 = rd<float>(fi, (size_t)n0 * 256), d1 = rd<float>(fi, (size_t)n1 * 256);
+        std::vector<Point2i> k0(n0), k1(n1);
+        if (mode == 2) {
+            auto x0 = rd<int32_t>(fi, (size_t)n0 * 2), x1 = rd<int32_t>(fi, (size_t)n1 * 2);
+            for (int i = 0; i < n0; i++) k0[i] = Point2i{ x0[2 * i], x0[2 * i + 1] };
+            for (int i = 0; i < n1; i++) k1[i] = Point2i{ x1[2 * i], x1[2 * i + 1] };
+        }
+        const float th = rd<float>(fi, 1)[0];
+        core::SuperpointFrontend fe(th);
+        DescMat m0{ d0.data(), n0 }, m1{ d1.data(), n1 };
+        auto res = mode == 2 ? fe.getStereoMatching(k0, m0, k1, m1) : fe.twoWayMatching(k0, m0, k1, m1);
+        if (fe.status() != VS_OK) { fprintf(stderr, "match: %s\n", fe.error().c_str()); return 3; }
+        const int32_t n = (int32_t)res.size();
+        wr(fo, &n, 1);
+        for (auto &r : res) { int32_t a = std::get<0>(r), b = std::get<1>(r); float d = std::get<2>(r); wr(fo, &a, 1); wr(fo, &b, 1); wr(fo, &d, 1); }
+    }
+    fclose(fi); fclose(fo);
+    return 0;
+}

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): rocprofv3 kernel traces + PMC traffic passes for the
+# round's evidence.  Usage: bash tools/collect_profiles.sh <round-tag>   -> gpurun_out/profiles_<tag>/
+set -u
+tag=${1:-r01}
+out=gpurun_out/profiles_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+run_trace() { # name, command...
+    local name=$1; shift
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -- "$@" > $out/$name.log 2>&1 || { echo "trace $name failed"; return 1; }
+    cp $out/$name/*/*_kernel_stats.csv $out/${name}_kernel_stats.csv
+}
+run_pmc() { # name, counters, command...
+    local name=$1; local ctr=$2; shift; shift
+    timeout -s KILL 120 rocprofv3 --pmc $ctr --output-format csv -d $out/$name -- "$@" > $out/$name.log 2>&1 || { echo "pmc $name failed"; return 1; }
+    cp $out/$name/*/*_counter_collection.csv $out/${name}_counters.csv
+}
+run_trace c2 python3 bench.py --steps 100 --warmup 10 --no-extra --no-cpu &&
+run_trace c4 python3 tools/prof_ba.py c4 20 &&
+run_trace c5shard python3 tools/prof_ba.py c5shard 20 &&
+run_trace match python3 tools/prof_match.py 64 3 &&
+run_pmc c2_fetch FETCH_SIZE python3 tools/prof_ba.py c2 5 &&
+run_pmc c2_write WRITE_SIZE python3 tools/prof_ba.py c2 5 &&
+run_pmc c4_fetch FETCH_SIZE python3 tools/prof_ba.py c4 5 &&
+run_pmc c4_write WRITE_SIZE python3 tools/prof_ba.py c4 5 &&
+run_pmc match_fetch FETCH_SIZE python3 tools/prof_match.py 16 2 &&
+run_pmc match_write WRITE_SIZE python3 tools/prof_match.py 16 2 &&
+run_pmc match_mfma "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" python3 tools/prof_match.py 16 2
+echo "profiles done rc=$?"
+# keep only the summaries (the raw per-dispatch traces are large)
+find $out -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+ls -la $out

@@ -1,6 +1,6 @@
 """Runs the BA linearisation a few times for profiling (python3 tools_prof_ba.py c2 [iters])."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import make_problem
 name = sys.argv[1] if len(sys.argv) > 1 else 'c2'

@@ -1,6 +1,6 @@
 """Runs the batched matcher a few times for profiling (python3 tools_prof_match.py [pairs] [iters])."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visual_slam_amd import matcher as vm
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 16

@@ -1,5 +1,5 @@
 import os, sys, json, subprocess
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 def run(name, waves, ept):
     env = dict(os.environ, VS_BA_ITEM_WAVES=str(waves), VS_BA_ITEM_EPT=str(ept))

@@ -909,6 +909,7 @@ int vs_match_stereo(const float *desc0, const int32_t *xy0, int32_t n0, const fl
                     const int32_t *xy1, int32_t n1, float nn_thresh, float ratio, int32_t *out_i,
                     int32_t *out_j, float *out_d, int32_t *out_n)
 {
+    if (out_n && (n0 == 0 || n1 == 0)) { *out_n = 0; return VS_OK; }
     VS_CHECK(xy0 && xy1, VS_ERR_INVALID, "stereo matching needs keypoint coordinates");
     return match_once(desc0, xy0, n0, desc1, xy1, n1, nn_thresh, ratio, out_i, out_j, out_d, out_n);
 }

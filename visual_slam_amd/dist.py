@@ -1,0 +1,63 @@
+"""Multi-GPU plumbing for the BA path: one process per GPU, landmarks sharded across ranks, the
+reduced camera system summed with one all-reduce (RCCL through torch.distributed's "nccl" backend
+on GPUs; "gloo" in the CPU tests).  The reference has no distributed path; the partition rule
+below is the one libvslam_hip.so applies in vs_ba_set_observations_sharded.
+"""
+import numpy as np
+
+
+def partition_landmarks(pt, n_points, world):
+    """Contiguous landmark ranges balanced by observation count.
+    Returns an array of world+1 landmark boundaries; rank r owns [b[r], b[r+1])."""
+    pt = np.asarray(pt)
+    counts = np.bincount(pt, minlength=n_points).astype(np.int64)
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    total = int(ptr[-1])
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    for r in range(1, world):
+        target = total * r // world
+        bounds[r] = min(int(np.searchsorted(ptr, target, side="left")), n_points)
+    bounds[world] = n_points
+    return np.maximum.accumulate(bounds)
+
+
+def shard_mask(pt, n_points, rank, world):
+    b = partition_landmarks(pt, n_points, world)
+    pt = np.asarray(pt)
+    return (pt >= b[rank]) & (pt < b[rank + 1])
+
+
+class _DevArray:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 2}
+
+
+def device_tensor(ptr, n):
+    """A torch float64 CUDA tensor aliasing `n` doubles at device address `ptr` (no copy)."""
+    import torch
+    return torch.as_tensor(_DevArray(ptr, n), device="cuda")
+
+
+def attach_allreduce(ba, group=None):
+    """Makes vs_ba_lm_step / vs_ba_solve of this rank's BAProblem sum the reduced camera system
+    (and the step scalars) across the process group before damping and solving."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(ptr, n):
+        t = device_tensor(ptr, n)
+        dist.all_reduce(t, group=group)
+        torch.cuda.current_stream().synchronize()
+
+    ba.set_allreduce(hook)
+    return ba
+
+
+def allreduce_sum_(array, group=None):
+    """In-place sum of a numpy float64 array across ranks (host path used by the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(array)
+    dist.all_reduce(t, group=group)
+    return array

@@ -95,7 +95,7 @@ struct vs_ba {
     DevBuf<CamData> cams;
     DevBuf<int> pt_ptr, lcam, lpt, lobs, cam_ptr, cpt, brow, bcol, bent;
     DevBuf<int> ditem_ptr, oitem_ptr;
-    DevBuf<BlockItem> items;
+    DevBuf<BlockItem> items, diag_items;
     DevBuf<unsigned char> cam_used, pt_used;
     DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
     DevBuf<real> scale_c, scale_p, lam_c, lam_c_user, lam_p_user, dcam, dpt, mcc_partial,
@@ -264,25 +264,33 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     if (const char *e = getenv("VS_BA_ITEM_WAVES")) h->item_waves = atoi(e) == 4 ? 4 : 1;   // tuning knobs
     if (const char *e = getenv("VS_BA_ITEM_EPT")) ept = std::max(1, atoi(e));
     const int ch = h->item_waves * kWave * ept;
-    std::vector<BlockItem> items;
+    // Items are listed block row by block row (camera c's diagonal item(s), then its
+    // off-diagonal blocks (c, c') in column order) so that a contiguous range of items is a band
+    // of cameras.  With fixed points only the diagonal items are launched (diag_items).
+    std::vector<BlockItem> items, diag_items;
     std::vector<int> di_ptr((size_t)Nc + 1, 0), oi_ptr((size_t)nb_off + 1, 0);
-    for (int c = 0; c < Nc; c++) {
-        const size_t first = items.size();
-        for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += ch)
-            items.push_back(BlockItem{ c, b, std::min(b + ch, cam_ptr[c + 1]), c, c, 0, 0, 0 });
-        di_ptr[c + 1] = (int)items.size();
-        if (items.size() - first == 1) items[first].single = 1;
-    }
-    const int n_diag_items = (int)items.size();
-    for (int k = 0; k < nb_off; k++) {
-        const size_t first = items.size();
-        for (int b = bptr[k]; b < bptr[k + 1]; b += ch)
-            items.push_back(BlockItem{ k, b, std::min(b + ch, bptr[k + 1]), h->h_brow[k], h->h_bcol[k], 0, 0, 0 });
-        oi_ptr[k + 1] = (int)items.size() - n_diag_items;
-        if (items.size() - first == 1) items[first].single = 1;
+    int n_diag_items = 0, n_off_items = 0;
+    {
+        int k = 0;   // off-diagonal blocks are sorted by (row, col): walk them row by row
+        for (int c = 0; c < Nc; c++) {
+            const size_t first = items.size();
+            for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += ch)
+                items.push_back(BlockItem{ c, b, std::min(b + ch, cam_ptr[c + 1]), c, c, 0, n_diag_items++, 0 });
+            di_ptr[c + 1] = n_diag_items;
+            if (items.size() - first == 1) items[first].single = 1;
+            for (size_t i = first; i < items.size(); i++) diag_items.push_back(items[i]);
+            for (; k < nb_off && h->h_brow[k] == c; k++) {
+                const size_t f2 = items.size();
+                for (int b = bptr[k]; b < bptr[k + 1]; b += ch)
+                    items.push_back(BlockItem{ k, b, std::min(b + ch, bptr[k + 1]), h->h_brow[k], h->h_bcol[k], 0, n_off_items++, 0 });
+                oi_ptr[k + 1] = n_off_items;
+                if (items.size() - f2 == 1) items[f2].single = 1;
+            }
+        }
+        for (int kk = 0; kk < nb_off; kk++) oi_ptr[kk + 1] = std::max(oi_ptr[kk + 1], oi_ptr[kk]);
     }
     h->n_diag_items = n_diag_items;
-    h->n_off_items = (int)items.size() - n_diag_items;
+    h->n_off_items = n_off_items;
     h->n_lm_blocks = div_up(Np, kLmThreads);
     h->n_lm4_blocks = div_up(Np, kLmPerBlock);
     h->stage_cams = (size_t)Nc * sizeof(CamData) <= 48 * 1024;
@@ -305,7 +313,9 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     auto up = [&](DevBuf<int> &d, std::vector<int> &v) { if (v.empty()) v.push_back(0); return d.upload(v.data(), v.size(), s); };
     VS_TRY(up(h->ditem_ptr, di_ptr)); VS_TRY(up(h->oitem_ptr, oi_ptr));
     if (items.empty()) items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
+    if (diag_items.empty()) diag_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
     VS_TRY(h->items.upload(items.data(), items.size(), s));
+    VS_TRY(h->diag_items.upload(diag_items.data(), diag_items.size(), s));
     VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
     VS_TRY(h->off_partial.alloc((size_t)std::max(h->n_off_items, 1) * kOffVals));
     VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm4_blocks, 1)));
@@ -344,15 +354,16 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     {
         // with fixed points only the camera (diagonal) items run
         const int n_items = h->n_diag_items + (h->fix_points ? 0 : h->n_off_items);
+        const BlockItem *list = h->fix_points ? h->diag_items.p : h->items.p;
         if (n_items > 0) {
             if (h->item_waves == 4)
-                hipLaunchKernelGGL(blocks_kernel<4>, dim3(n_items), dim3(4 * kWave), 0, h->stream, h->n_diag_items,
-                                   h->items.p, h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
+                hipLaunchKernelGGL(blocks_kernel<4>, dim3(n_items), dim3(4 * kWave), 0, h->stream, n_items, list,
+                                   h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
                                    h->Nc, h->nb_off);
             else
-                hipLaunchKernelGGL(blocks_kernel<1>, dim3(n_items), dim3(kWave), 0, h->stream, h->n_diag_items,
-                                   h->items.p, h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
+                hipLaunchKernelGGL(blocks_kernel<1>, dim3(n_items), dim3(kWave), 0, h->stream, n_items, list,
+                                   h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
                                    h->Nc, h->nb_off);
             VS_TRY(launch_check("blocks_kernel"));

@@ -451,7 +451,8 @@ struct BlockItem {
     int begin, end; // entry range: camera-major observations, or camera-pair entries
     int ca, cb;     // the block's cameras (ca == cb for a diagonal item)
     int single;     // the block consists of this item only: write the final values directly
-    int pad0, pad1;
+    int slot;       // row of diag_partial / off_partial this item writes when not single
+    int pad1;
 };
 static_assert(sizeof(BlockItem) == 32, "BlockItem is 32 bytes");
 
@@ -464,18 +465,17 @@ __device__ __forceinline__ void load_rec(const real *__restrict__ lmrec, int j, 
 }
 
 // (a)+(b), block side: one workgroup of WAVES waves per work item.
-//   items [0, n_diag_items): a slice of one camera's observations (camera-major view).  Per
+//   diagonal items (ca == cb): a slice of one camera's observations (camera-major view).  Per
 //     observation, with N = I - Jp Vinv Jp^T (2x2; N = I when points are fixed):
 //       S_cc += Jc^T N Jc,  rhs += Jc^T (Jp Vinv g_p - r),  diag(U) += diag(Jc^T Jc),  g_c += Jc^T r
-//   items [n_diag_items, n_items): a slice of the landmarks seen by both cameras a < b of one
-//     off-diagonal block:  S_ab -= Jc_a^T (Jp_a Vinv Jp_b^T) Jc_b.
+//   off-diagonal items: a slice of the landmarks seen by both cameras a < b of one block:  S_ab -= Jc_a^T (Jp_a Vinv Jp_b^T) Jc_b.
 // r, Jc, Jp are recomputed from the parameters (J is never stored).  The next entry's landmark
 // record is loaded while the current one is processed.  A block made of a single item is written
 // straight into the reduce buffer, otherwise a per-item partial is written and finalize_kernel
 // adds the partials in item order.
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES *kWave)
-blocks_kernel(int n_diag_items, const BlockItem *__restrict__ items, Intr K,
+blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
               const CamData *__restrict__ cams, const real *__restrict__ lmrec,
               const int *__restrict__ cpt, const real *__restrict__ cuv,
               const int *__restrict__ bent, HuberObs hub, const real *__restrict__ hub_w,
@@ -487,11 +487,18 @@ blocks_kernel(int n_diag_items, const BlockItem *__restrict__ items, Intr K,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     real *lds_wave = lds + wave * 21 * kRedStride;
     real *xw = lds + WAVES * 21 * kRedStride;
-    const int item = blockIdx.x;
+    // XCD-aware order: workgroups sharing an XCD (blockIdx.x % 8) take one contiguous eighth of
+    // the item list, i.e. a band of cameras, so the landmark records that band's blocks share
+    // stay in that XCD's L2.
+    int item = blockIdx.x;
+    {
+        const int q = n_items >> 3, r = n_items & 7, x = item & 7, w = item >> 3;
+        item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
+    }
     const BlockItem it = items[item];
     const RedView rv = red_view(red, Nc, nb_off);
     constexpr int kStride = WAVES * kWave;
-    if (item < n_diag_items) {
+    if (it.ca == it.cb) {
         real acc[kDiagVals];
 #pragma unroll
         for (int v = 0; v < kDiagVals; v++) acc[v] = real(0);
@@ -563,8 +570,8 @@ blocks_kernel(int n_diag_items, const BlockItem *__restrict__ items, Intr K,
                 if (lane < 21) store_diag_value(rv, it.blk, lane, s1);
                 if (lane < 18) store_diag_value(rv, it.blk, 21 + lane, s2);
             } else {
-                if (lane < 21) diag_partial[(int64_t)item * kDiagVals + lane] = s1;
-                if (lane < 18) diag_partial[(int64_t)item * kDiagVals + 21 + lane] = s2;
+                if (lane < 21) diag_partial[(int64_t)it.slot * kDiagVals + lane] = s1;
+                if (lane < 18) diag_partial[(int64_t)it.slot * kDiagVals + 21 + lane] = s2;
             }
         }
     } else {
@@ -634,7 +641,7 @@ blocks_kernel(int n_diag_items, const BlockItem *__restrict__ items, Intr K,
         const real s2 = group_reduce<18, WAVES>(acc + 18, lds_wave, xw, lane, wave);
         if (wave == 0 && lane < 18) {
             real *dst = it.single ? rv.S_off + (int64_t)it.blk * 36
-                                  : off_partial + (int64_t)(item - n_diag_items) * kOffVals;
+                                  : off_partial + (int64_t)it.slot * kOffVals;
             dst[lane] = s1;
             dst[18 + lane] = s2;
         }

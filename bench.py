@@ -65,17 +65,17 @@ def bench_ba(args, rank, world, dist, torch):
     pp = C.cast(C.c_void_p(dp.data_ptr()), C.POINTER(C.c_double))
     assert lib.vs_ba_linearize(ba.h, pc, pp) == 0
     ptr, n = ba.reduce_buffer()
-    red = torch.as_tensor(_DevArray(ptr, n), device="cuda") if world > 1 else None
+    red = torch.as_tensor(_DevArray(ptr, n), device="cuda") if dist is not None else None
     setup_s = time.time() - t0
 
     def step():
         rc = lib.vs_ba_linearize(ba.h, pc, pp)
         assert rc == 0
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(red)
 
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5shard"])
     ap.add_argument("--no-extra", action="store_true", help="skip the matcher leg and larger BA shapes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise a process group and all-reduce even with one rank (rehearsal of the N>1 path)")
     args = ap.parse_args()
 
     import torch
@@ -232,9 +234,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     ba = bench_ba(args, rank, world, dist, torch)
     extra = {}
     if not args.no_extra:
@@ -261,7 +266,7 @@ def main():
             line["cpu_baseline"] = None
         line["extra"] = extra
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -2,16 +2,18 @@
 //
 // Exactness plan.  The reference decides nearest neighbours on
 //   d(i,j) = sqrtf(2 - 2*clamp((float)dot64(desc0_i, desc1_j), -1, 1)),  first minimum wins.
-// The dense 4096 x 4096 x 256 contraction runs on the matrix cores with fp16 operands:
-// every descriptor (scaled by 2^8) is split into hi + lo fp16 parts and the kernel accumulates
-// hi*hi + hi*lo + lo*hi in fp32, i.e. an fp32-accurate dot s~ with |s~ - s| <= kEps for unit
-// descriptors (split residue <= 3*2^-22, fp32 accumulation of 768 products <= 768*2^-23).  A fused
-// epilogue keeps, per row and per column, the best and second-best s~.  Where best - second
-// exceeds 2*kEps + kCollapse (kCollapse covers distinct dots that the fp32 clamp/sqrt chain maps
-// to one float), the approximate winner provably is the reference's first minimum and only its
-// distance is recomputed exactly; otherwise the row/column is re-decided by an exact scan that
-// replays the reference arithmetic (sequential fp64 accumulation, narrowing, clamp, sqrtf).
-// Indices and distances are therefore bit-identical to the reference path.
+// The dense 4096 x 4096 x 256 contraction runs on the matrix cores with fp16 operands: every
+// descriptor (scaled by 2^8) is rounded to fp16 and the kernel accumulates the products in fp32.
+// The rounding kernel also measures, per frame pair, the largest rounding residue ||a - a16|| and
+// the largest ||a16|| of each side, which give a certified bound eps on |s~ - s| for every entry
+// of that pair (Cauchy-Schwarz on the residues + fp32 accumulation of 256 products + the index
+// packing of the epilogue).  A fused epilogue keeps, per row and per column, the best and
+// second-best s~.  Where best - second exceeds 2*eps + kCollapse (kCollapse covers distinct dots
+// that the fp32 clamp/sqrt chain maps to one float), the approximate winner provably is the
+// reference's first minimum and only its distance is recomputed exactly; otherwise the row/column
+// is re-decided by an exact scan that replays the reference arithmetic (sequential fp64
+// accumulation, narrowing, clamp, sqrtf).  Indices and distances are therefore bit-identical to
+// the reference path.
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -28,36 +30,74 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kD = VS_DESC_DIM;        // 256
 constexpr int kBM = 128, kBN = 128;    // workgroup tile
-constexpr int kBK = 32;                // halfs per K-step
-constexpr int kRowH = kBK + 8;         // padded LDS row (80 B): conflict-free ds_read_b128
+constexpr int kBK = 64;                // halfs per K-step
 constexpr int kSub = 64;               // rows/cols covered by one wave = granularity of partials
 constexpr float kScale = 256.0f;       // descriptor prescale (2^8), dot prescale 2^16
 constexpr float kDotScale = 65536.0f;
-constexpr float kEps = 1.1e-4f;        // bound on |s~ - s| (fp16 split + fp32 accumulation 1e-4, index packing 8e-6)
 constexpr float kCollapse = 1.0e-6f;   // dots closer than this may share one fp32 distance
-constexpr float kBand = (2.0f * kEps + kCollapse) * kDotScale;
+// relative (to ||a16|| ||b16||) error of the fp32 accumulation of 256 products (256 * 2^-23) and of
+// the epilogue's index packing into the low 6 mantissa bits (2^-17)
+constexpr float kAccumRel = 256.0f * 1.1920929e-7f + 7.6293945e-6f;
 constexpr float kNegInf = -3.0e38f;
 constexpr float kMaskedDot = 0.5f * kDotScale;   // distance 1.0  <=>  dot 0.5
 
-// fp32 rows -> hi/lo fp16 rows (n_pad rows, rows >= n zero-filled).
+constexpr int kSplitRows = 32;          // rows per workgroup of split_kernel
+
+// fp32 rows -> fp16 rows scaled by 2^8 (n_pad rows, rows >= n zero-filled).  One wave per row,
+// kSplitRows rows per workgroup.
+// stats[0] / stats[1] receive the maxima over rows of ||x - x16||^2 and ||x16||^2 (scaled units),
+// as float bit patterns (non-negative floats order like unsigned integers).
 __global__ void __launch_bounds__(256)
 split_kernel(const float *__restrict__ src, int n, int n_pad, _Float16 *__restrict__ hi,
-             _Float16 *__restrict__ lo)
+             unsigned *__restrict__ stats)
 {
-    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= (int64_t)n_pad * kD) return;
-    const int row = (int)(e / kD);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < n) v = *reinterpret_cast<const float4 *>(src + e);
-    const float x[4] = { v.x * kScale, v.y * kScale, v.z * kScale, v.w * kScale };
-    _Float16 h[4], l[4];
+    __shared__ float wmax[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float res_max = 0.f, nrm_max = 0.f;
+    for (int q = 0; q < kSplitRows / 4; q++) {
+        const int row = blockIdx.x * kSplitRows + q * 4 + wave;
+        if (row >= n_pad) break;
+        const int64_t e = (int64_t)row * kD + lane * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n) v = *reinterpret_cast<const float4 *>(src + e);
+        const float x[4] = { v.x * kScale, v.y * kScale, v.z * kScale, v.w * kScale };
+        _Float16 h[4];
+        float res2 = 0.f, nrm2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        h[k] = (_Float16)x[k];
-        l[k] = (_Float16)(x[k] - (float)h[k]);
+        for (int k = 0; k < 4; k++) {
+            h[k] = (_Float16)x[k];
+            const float hf = (float)h[k], r = x[k] - hf;    // the residue is exact in fp32
+            res2 = fmaf(r, r, res2);
+            nrm2 = fmaf(hf, hf, nrm2);
+        }
+        *reinterpret_cast<uint2 *>(hi + e) = *reinterpret_cast<uint2 *>(h);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            res2 += __shfl_xor(res2, off, 64);
+            nrm2 += __shfl_xor(nrm2, off, 64);
+        }
+        res_max = fmaxf(res_max, res2);
+        nrm_max = fmaxf(nrm_max, nrm2);
     }
-    *reinterpret_cast<uint2 *>(hi + e) = *reinterpret_cast<uint2 *>(h);
-    *reinterpret_cast<uint2 *>(lo + e) = *reinterpret_cast<uint2 *>(l);
+    if (lane == 0) { wmax[0][wave] = res_max; wmax[1][wave] = nrm_max; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float m = fmaxf(fmaxf(wmax[threadIdx.x][0], wmax[threadIdx.x][1]),
+                              fmaxf(wmax[threadIdx.x][2], wmax[threadIdx.x][3]));
+        atomicMax(stats + threadIdx.x, __float_as_uint(m));
+    }
+}
+
+// Certainty band of one frame pair in units of s~ (= 2^16 * dot): twice the bound on |s~ - s|
+// plus the collapse margin.  stats = { max||a-a16||^2, max||a16||^2, max||b-b16||^2, max||b16||^2 }.
+__device__ __forceinline__ float pair_band(const unsigned *__restrict__ stats, int pair)
+{
+    const uint4 q = *reinterpret_cast<const uint4 *>(stats + 4 * (int64_t)pair);
+    // 0.2 % inflation covers the fp32 rounding of the sums of squares and of this formula
+    const float ea = sqrtf(__uint_as_float(q.x)) * 1.002f, na = sqrtf(__uint_as_float(q.y)) * 1.002f;
+    const float eb = sqrtf(__uint_as_float(q.z)) * 1.002f, nb = sqrtf(__uint_as_float(q.w)) * 1.002f;
+    const float eps = ea * (nb + eb) + na * eb + kAccumRel * na * nb;
+    return 2.0f * eps * 1.002f + kCollapse * kDotScale;
 }
 
 // plain VALU max / median without the canonicalising extra instructions the compiler adds
@@ -74,100 +114,113 @@ __device__ __forceinline__ float vmed3(float a, float b, float c)
     return r;
 }
 
-struct Top2 {
-    float b1, b2;
-    int i1;
-};
-
-__device__ __forceinline__ void top2_push(Top2 &t, float v, int idx)
+// union of two (best, second) pairs of packed scores
+__device__ __forceinline__ void top2_union(float &b1, float &b2, float ob1, float ob2)
 {
-    if (v > t.b1) { t.b2 = t.b1; t.b1 = v; t.i1 = idx; }
-    else t.b2 = fmaxf(t.b2, v);
-}
-
-// merge (ob1, oi1, ob2) into t; equal bests leave b2 == b1 (gap 0 => decided exactly later)
-__device__ __forceinline__ void top2_merge(Top2 &t, float ob1, int oi1, float ob2)
-{
-    if (ob1 > t.b1) { t.b2 = fmaxf(t.b1, ob2); t.b1 = ob1; t.i1 = oi1; }
-    else t.b2 = fmaxf(t.b2, ob1);
+    const float lo = fminf(b1, ob1);
+    b1 = fmaxf(b1, ob1);
+    b2 = fmaxf(lo, fmaxf(b2, ob2));
 }
 
 struct PairDims {
     int n0, n1;
 };
 
-// One workgroup = one 128 x 128 tile of s~ = 2^16 * desc0 . desc1 for one frame pair; 4 waves,
-// each a 64 x 64 sub-tile as 2 x 2 MFMA 32x32x16 f16 tiles.  Epilogue: per-column top-2 over the
-// wave's 64 rows (in registers) and per-row top-2 over its 64 columns (transposed through LDS).
-template <bool MASKED>
-__global__ void __launch_bounds__(256)
-dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ a_lo,
-                const _Float16 *__restrict__ b_hi, const _Float16 *__restrict__ b_lo,
-                const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
-                const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
-                float *__restrict__ row_b1, int *__restrict__ row_i1, float *__restrict__ row_b2,
-                float *__restrict__ col_b1, int *__restrict__ col_i1, float *__restrict__ col_b2)
-{
-    // staging: 4 operand tiles of 128 x kRowH halfs; epilogue: 4 waves x 32 x 65 floats
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * kBM * kRowH * 2];
-    _Float16 *sA_hi = reinterpret_cast<_Float16 *>(smem);
-    _Float16 *sA_lo = sA_hi + kBM * kRowH;
-    _Float16 *sB_hi = sA_lo + kBM * kRowH;
-    _Float16 *sB_lo = sB_hi + kBN * kRowH;
+// LDS image of one streamed desc1 K-step: kBN rows (columns of the score tile) x kBK halfs,
+// unpadded 128-byte rows whose eight 16-byte chunks are XOR-swizzled with (row >> 1) & 7, which
+// makes the ds_read_b128 fragment reads conflict-free.  The image is filled by LDS-DMA
+// (global_load_lds_dwordx4: destination = wave-uniform base + 16 * lane), so the swizzle is applied
+// to the per-lane SOURCE address and again to the read address.
+constexpr int kStageBytes = kBN * kBK * 2;              // 16 KiB
+constexpr int kTS = 68;                                 // transpose row stride in floats
+constexpr int kDotLds = 2 * kStageBytes + 4 * 32 * kTS * 4;
 
-    const int pair = blockIdx.z;
-    const int ntc = n1_pad / kBN, ntr = n0_pad / kBM;
-    (void)ntc;
-    // XCD-aware tile order: workgroups that land on one XCD (blockIdx.x % 8) take a band of
-    // `rpx` tile rows and walk it column by column, so the band's A rows stay in that XCD's L2
-    // and each B panel is fetched once per band instead of once per tile row.
-    int tile_r, tile_c;
-    {
-        const int lin = blockIdx.x;
-        if ((ntr & 7) == 0) {
-            const int rpx = ntr >> 3;                  // tile rows per XCD
-            const int q = lin >> 3;                    // position inside the XCD's band
-            tile_r = (lin & 7) * rpx + q % rpx;
-            tile_c = q / rpx;
-        } else {
-            tile_r = lin / ntc;
-            tile_c = lin % ntc;
-        }
-    }
-    const int n0 = dims[pair].n0, n1 = dims[pair].n1;
-    const int i0 = tile_r * kBM, j0 = tile_c * kBN;
-    if (i0 >= n0 || j0 >= n1) return;   // tile fully outside this pair: nothing reads its partials
-    const _Float16 *gA_hi = a_hi + ((int64_t)pair * n0_pad + i0) * kD;
-    const _Float16 *gA_lo = a_lo + ((int64_t)pair * n0_pad + i0) * kD;
-    const _Float16 *gB_hi = b_hi + ((int64_t)pair * n1_pad + j0) * kD;
-    const _Float16 *gB_lo = b_lo + ((int64_t)pair * n1_pad + j0) * kD;
+// One workgroup = one band: kBM rows of desc0 of one frame pair against `tiles_per_wg` consecutive
+// kBN-column tiles of desc1.  4 waves, each a 64 x 64 sub-tile as 2 x 2 MFMA 32x32x16 f16 tiles.
+// Every wave keeps the fp16 fragments of its 64 desc0 rows (all 256 k) in registers for the whole
+// band; desc1 streams through a two-stage LDS ring, one barrier per K-step, the DMA of the next
+// K-step (also across tile boundaries) in flight behind the MFMAs and the epilogue of the current
+// one.  Epilogue: per-column top-2 over the wave's 64 rows (in registers) and per-row top-2 over
+// its 64 columns (transposed through a wave-private LDS area, no barrier).
+template <bool MASKED>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b16,
+                const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
+                const int2 *__restrict__ xy1, int n0_pad, int n1_pad, int tiles_per_wg,
+                float2 *__restrict__ row_part, float2 *__restrict__ col_part)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kDotLds];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
 
-    // staging map: 128 rows x 4 chunks of 16 B per operand tile; 2 chunks per thread, held in
-    // named registers (an indexed array would be demoted to scratch memory)
-    static_assert(kBK == 32, "staging map below is written for 32-half K-steps");
-    const int c0 = tid, c1 = tid + 256;
-    const int64_t g0 = (int64_t)(c0 >> 2) * kD + (c0 & 3) * 8, g1 = (int64_t)(c1 >> 2) * kD + (c1 & 3) * 8;
-    const int l0 = (c0 >> 2) * kRowH + (c0 & 3) * 8, l1 = (c1 >> 2) * kRowH + (c1 & 3) * 8;
-    uint4 ra0, ra1, rb0, rb1, rc0, rc1, rd0, rd1;
-#define VS_LD4(r, base, ko)                                                                \
-    r##0 = *reinterpret_cast<const uint4 *>(base + g0 + ko);                               \
-    r##1 = *reinterpret_cast<const uint4 *>(base + g1 + ko)
-#define VS_ST4(r, base)                                                                    \
-    *reinterpret_cast<uint4 *>(base + l0) = r##0;                                          \
-    *reinterpret_cast<uint4 *>(base + l1) = r##1
-#define VS_LOAD_TILE(kt)                                                                   \
-    do {                                                                                   \
-        const int ko = (kt) * kBK;                                                         \
-        VS_LD4(ra, gA_hi, ko); VS_LD4(rb, gA_lo, ko); VS_LD4(rc, gB_hi, ko); VS_LD4(rd, gB_lo, ko); \
-    } while (0)
-#define VS_STORE_TILE()                                                                    \
-    do {                                                                                   \
-        VS_ST4(ra, sA_hi); VS_ST4(rb, sA_lo); VS_ST4(rc, sB_hi); VS_ST4(rd, sB_lo);        \
+    // band decode; workgroups that share an XCD (blockIdx.x % 8) take a contiguous range of
+    // bands, so an XCD's L2 holds the desc1 rows of one or two frame pairs at a time
+    const int ntr = n0_pad / kBM, ntc = n1_pad / kBN;
+    const int splits = (ntc + tiles_per_wg - 1) / tiles_per_wg;
+    const int bands_per_pair = ntr * splits;
+    int band;
+    {
+        const int total = gridDim.x, x = blockIdx.x & 7, w = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        band = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
+    }
+    const int pair = band / bands_per_pair;
+    const int tile_r = (band % bands_per_pair) / splits, split = band % splits;
+    const int n0 = dims[pair].n0, n1 = dims[pair].n1;
+    const int i0 = tile_r * kBM;
+    const int c_begin = split * tiles_per_wg;
+    const int c_end = min(min(ntc, c_begin + tiles_per_wg), (n1 + kBN - 1) / kBN);
+    if (i0 >= n0 || c_begin >= c_end) return;   // band outside this pair: nothing reads its partials
+
+    // desc0 fragments of a 32x32x16 MFMA: lane holds 8 consecutive k of row (lane & 31), k offset
+    // 8 * (lane >> 5); 2 row tiles x 16 k-steps = 128 VGPRs
+    half8 af[2][kD / 16];
+    {
+        const _Float16 *gA = a16 + ((int64_t)pair * n0_pad + i0 + wr * 64 + l31) * kD + half * 8;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int ks = 0; ks < kD / 16; ks++)
+                af[m][ks] = *reinterpret_cast<const half8 *>(gA + (int64_t)m * 32 * kD + ks * 16);
+    }
+
+    // LDS-DMA map: a stage is 16 wave-instructions of 8 rows x 128 B; wave w fills rows
+    // [32 w, 32 w + 32).  Lane l writes chunk slot (l & 7) of row 8 q + (l >> 3) and therefore
+    // fetches source chunk (l & 7) ^ ((row >> 1) & 7).
+    int src_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int row = wave * 32 + q * 8 + (lane >> 3);
+        src_off[q] = row * kD + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    }
+    const _Float16 *gB = b16 + (int64_t)pair * n1_pad * kD;
+    const int n_stages = (c_end - c_begin) * (kD / kBK);
+#define VS_ISSUE_STAGE(s_)                                                                     \
+    do {                                                                                       \
+        const int st_ = (s_);                                                                  \
+        const _Float16 *g_ = gB + (int64_t)(c_begin + st_ / (kD / kBK)) * kBN * kD + (st_ % (kD / kBK)) * kBK; \
+        unsigned char *l_ = smem + (st_ & 1) * kStageBytes + wave * 4096;                      \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[0]), \
+                                         (__attribute__((address_space(3))) void *)(l_), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[1]), \
+                                         (__attribute__((address_space(3))) void *)(l_ + 1024), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[2]), \
+                                         (__attribute__((address_space(3))) void *)(l_ + 2048), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[3]), \
+                                         (__attribute__((address_space(3))) void *)(l_ + 3072), 16, 0, 0);  \
     } while (0)
 
+    // fragment read offsets inside a stage: column wc*64 + n*32 + l31, chunk (2 ks + half) ^ swz
+    const int swz = (l31 >> 1) & 7;
+    const int frag_row = (wc * 64 + l31) * (kBK * 2);
+
+    float *sT = reinterpret_cast<float *>(smem + 2 * kStageBytes) + wave * (32 * kTS);
+
+    VS_ISSUE_STAGE(0);
+    for (int tc = c_begin; tc < c_end; tc++) {
+    const int j0 = tc * kBN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -176,53 +229,33 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-    VS_LOAD_TILE(0);
-    constexpr int kSteps = kD / kBK;
-    for (int kt = 0; kt < kSteps; kt++) {
-        __syncthreads();
-        VS_STORE_TILE();
-        __syncthreads();
-        if (kt + 1 < kSteps) VS_LOAD_TILE(kt + 1);
-        // keep the prefetch in front of the MFMA block (the scheduler otherwise sinks the loads
-        // to the end of the iteration, exposing their whole latency at the next barrier)
+#pragma unroll
+    for (int kt = 0; kt < kD / kBK; kt++) {
+        const int s = (tc - c_begin) * (kD / kBK) + kt;
+        // this wave's share of stage s has landed; after the barrier every wave's has, and every
+        // wave has finished reading the other buffer (stage s - 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < n_stages) VS_ISSUE_STAGE(s + 1);
+        const unsigned char *buf = smem + (s & 1) * kStageBytes + frag_row;
 #pragma unroll
         for (int ks = 0; ks < kBK / 16; ks++) {
-            // fragment of a 32x32x16 MFMA: lane holds 8 consecutive k of row/col (lane & 31),
-            // k offset 8 * (lane >> 5)
-            const int koff = ks * 16 + (lane >> 5) * 8;
-            half8 ah[2], al[2], bh[2], bl[2];
+            half8 bf[2];
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const int row = wr * 64 + m * 32 + (lane & 31);
-                ah[m] = *reinterpret_cast<const half8 *>(sA_hi + row * kRowH + koff);
-                al[m] = *reinterpret_cast<const half8 *>(sA_lo + row * kRowH + koff);
-            }
-#pragma unroll
-            for (int n = 0; n < 2; n++) {
-                const int col = wc * 64 + n * 32 + (lane & 31);
-                bh[n] = *reinterpret_cast<const half8 *>(sB_hi + col * kRowH + koff);
-                bl[n] = *reinterpret_cast<const half8 *>(sB_lo + col * kRowH + koff);
-            }
+            for (int n = 0; n < 2; n++)
+                bf[n] = *reinterpret_cast<const half8 *>(buf + n * 32 * (kBK * 2) + (((2 * ks + half) ^ swz) * 16));
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int n = 0; n < 2; n++) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-                }
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][kt * (kBK / 16) + ks], bf[n], acc[m][n], 0, 0, 0);
         }
     }
 
-#undef VS_LOAD_TILE
-#undef VS_STORE_TILE
-#undef VS_LD4
-#undef VS_ST4
     // ---- epilogue --------------------------------------------------------------------------
     // element (m, n, r) of this lane: row gi = i0 + wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
     //                                 col gj = j0 + wc*64 + n*32 + (lane&31)
-    const int half = lane >> 5, l31 = lane & 31;
     const bool partial_tile = i0 + kBM > n0 || j0 + kBN > n1;      // workgroup-uniform
     if (MASKED || partial_tile) {
 #pragma unroll
@@ -247,16 +280,20 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
                 }
         }
     }
-    // running top-2 on PACKED scores: the low 6 mantissa bits of each score carry the element
-    // number (relative perturbation <= 2^-17, inside kEps), so no index needs tracking:
+    // running top-2 on PACKED scores: the low 6 mantissa bits of each score carry the element's
+    // position inside the wave's 64 rows / columns (relative perturbation <= 2^-17, part of the
+    // band), so no index needs tracking:
     //   b2 <- median(b1, b2, key);  b1 <- max(b1, key)         (2 VALU + 1 pack per element)
+    // Each lane packs a 5-bit position; bit 5 (= lane half) is set once on the lane's best.
 #define VS_TOP2_STEP(v, e)                                                                  \
     do {                                                                                     \
         const float k_ = __uint_as_float((__float_as_uint(v) & 0xffffffc0u) | (unsigned)(e)); \
         b2 = vmed3(b1, b2, k_);                                                              \
         b1 = vmax(b1, k_);                                                                   \
     } while (0)
-    // columns: top-2 over the wave's 64 rows
+    const unsigned half_bit = (unsigned)half << 5;
+    // columns: top-2 over the wave's 64 rows; position code e = 32*half + 16*m + r stands for
+    // row m*32 + (r&3) + 8*(r>>2) + 4*half of the wave's 64 (decoded by col_position())
 #pragma unroll
     for (int n = 0; n < 2; n++) {
         float b1 = kNegInf, b2 = kNegInf;
@@ -264,31 +301,23 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
         for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) VS_TOP2_STEP(acc[m][n][r], m * 16 + r);
-        const int e1 = (int)(__float_as_uint(b1) & 63u);
-        const int rr = e1 & 15;
-        Top2 t{ b1, b2, i0 + wr * 64 + (e1 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half };
-        const float ob1 = __shfl_xor(t.b1, 32, 64), ob2 = __shfl_xor(t.b2, 32, 64);
-        const int oi1 = __shfl_xor(t.i1, 32, 64);
-        top2_merge(t, ob1, oi1, ob2);
+        b1 = __uint_as_float(__float_as_uint(b1) | half_bit);
+        top2_union(b1, b2, __shfl_xor(b1, 32, 64), __shfl_xor(b2, 32, 64));
         if (half == 0) {
             const int64_t o = ((int64_t)pair * (n0_pad / kSub) + (i0 / kSub + wr)) * n1_pad + j0 + wc * 64 + n * 32 + l31;
-            col_b1[o] = t.b1; col_i1[o] = t.i1; col_b2[o] = t.b2;
+            col_part[o] = make_float2(b1, b2);
         }
     }
-    // rows: transpose 32 rows x 64 cols at a time through LDS (row stride 68 floats keeps the
-    // float4 reads aligned and conflict-free)
-    constexpr int kTS = 68;
-    float *sT = reinterpret_cast<float *>(smem) + wave * (32 * kTS);
-    static_assert(4 * 32 * kTS * 4 <= (int)sizeof(smem), "transpose scratch fits the staging LDS");
+    // rows: transpose 32 rows x 64 cols at a time through the wave's own LDS area (row stride 68
+    // floats keeps the float4 reads aligned and conflict-free; a wave's LDS operations complete in
+    // issue order, so no barrier is needed); position code = column inside the wave's 64
 #pragma unroll
     for (int m = 0; m < 2; m++) {
-        __syncthreads();
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 sT[((r & 3) + 8 * (r >> 2) + 4 * half) * kTS + n * 32 + l31] = acc[m][n][r];
-        __syncthreads();
         float b1 = kNegInf, b2 = kNegInf;
         const float4 *rowp = reinterpret_cast<const float4 *>(sT + l31 * kTS + 32 * half);
 #pragma unroll
@@ -297,41 +326,83 @@ dot_top2_kernel(const _Float16 *__restrict__ a_hi, const _Float16 *__restrict__ 
             VS_TOP2_STEP(q.x, 4 * c); VS_TOP2_STEP(q.y, 4 * c + 1);
             VS_TOP2_STEP(q.z, 4 * c + 2); VS_TOP2_STEP(q.w, 4 * c + 3);
         }
-        const int e1 = (int)(__float_as_uint(b1) & 63u);
-        Top2 t{ b1, b2, j0 + wc * 64 + 32 * half + e1 };
-        const float ob1 = __shfl_xor(t.b1, 32, 64), ob2 = __shfl_xor(t.b2, 32, 64);
-        const int oi1 = __shfl_xor(t.i1, 32, 64);
-        top2_merge(t, ob1, oi1, ob2);
+        b1 = __uint_as_float(__float_as_uint(b1) | half_bit);
+        top2_union(b1, b2, __shfl_xor(b1, 32, 64), __shfl_xor(b2, 32, 64));
         if (half == 0) {
             const int64_t o = ((int64_t)pair * (n1_pad / kSub) + (j0 / kSub + wc)) * n0_pad + i0 + wr * 64 + m * 32 + l31;
-            row_b1[o] = t.b1; row_i1[o] = t.i1; row_b2[o] = t.b2;
+            row_part[o] = make_float2(b1, b2);
         }
     }
+    }   // column tiles of the band
 #undef VS_TOP2_STEP
+#undef VS_ISSUE_STAGE
 }
 
-// Merge the per-64 partials of one row (dir 0) or column (dir 1); decide whether the approximate
-// winner is certain.  One thread per item.
+// position code of a column partial -> row inside the wave's 64 rows
+__device__ __forceinline__ int col_position(unsigned code)
+{
+    const int rr = code & 15, m = (code >> 4) & 1, half = (code >> 5) & 1;
+    return m * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+}
+// candidate index named by the packed best of chunk `p` (rows: a column; columns: a row)
+__device__ __forceinline__ int partial_index(bool is_row, int p, float packed_b1)
+{
+    const unsigned code = __float_as_uint(packed_b1) & 63u;
+    return p * kSub + (is_row ? (int)code : col_position(code));
+}
+
+// Partials of item `it` of a pair (it < n0_pad: row it; else column it - n0_pad): chunk p of the
+// other side lives at part[p * stride].
+struct ItemView {
+    const float2 *part;
+    int64_t stride;
+    int n_cand, self;
+    bool is_row;
+};
+__device__ __forceinline__ ItemView item_view(int pair, int it, PairDims d, int n0_pad, int n1_pad,
+                                              const float2 *row_part, const float2 *col_part)
+{
+    ItemView v;
+    v.is_row = it < n0_pad;
+    v.self = v.is_row ? it : it - n0_pad;
+    v.n_cand = v.is_row ? d.n1 : d.n0;
+    v.stride = v.is_row ? n0_pad : n1_pad;
+    v.part = v.is_row ? row_part + (int64_t)pair * (n1_pad / kSub) * n0_pad + v.self
+                      : col_part + (int64_t)pair * (n0_pad / kSub) * n1_pad + v.self;
+    return v;
+}
+
+// Merge the per-64 partials of every row and column; store the approximate winner and list the
+// items whose winner is not certain (all rows when force_rows is set).  One thread per item.
 __global__ void __launch_bounds__(256)
-merge_kernel(const PairDims *__restrict__ dims, int n_pad_items, int n_parts,
-             int dir, const float *__restrict__ b1, const int *__restrict__ i1,
-             const float *__restrict__ b2, int *__restrict__ nn_idx,
-             unsigned char *__restrict__ uncertain, float *__restrict__ best, int force_uncertain)
+merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
+             const float2 *__restrict__ row_part, const float2 *__restrict__ col_part,
+             const unsigned *__restrict__ stats, int *__restrict__ idx0, int *__restrict__ idx1,
+             int *__restrict__ rescan_list, int *__restrict__ rescan_count, int force_rows)
 {
     const int pair = blockIdx.y;
     const int it = blockIdx.x * 256 + threadIdx.x;
-    const int n_items = dir == 0 ? dims[pair].n0 : dims[pair].n1;
-    const int n_other = dir == 0 ? dims[pair].n1 : dims[pair].n0;
-    if (it >= n_items) return;
-    Top2 t{ kNegInf, kNegInf, 0 };
-    const int parts = (n_other + kSub - 1) / kSub;
+    if (it >= n0_pad + n1_pad) return;
+    const PairDims d = dims[pair];
+    const ItemView v = item_view(pair, it, d, n0_pad, n1_pad, row_part, col_part);
+    if (v.self >= (v.is_row ? d.n0 : d.n1)) return;
+    float b1 = kNegInf, b2 = kNegInf;
+    int pbest = 0;
+    const int parts = (v.n_cand + kSub - 1) / kSub;
     for (int p = 0; p < parts; p++) {
-        const int64_t o = ((int64_t)pair * n_parts + p) * n_pad_items + it;
-        top2_merge(t, b1[o], i1[o], b2[o]);
+        const float2 q = v.part[p * v.stride];
+        if (q.x > b1) pbest = p;
+        top2_union(b1, b2, q.x, q.y);
     }
-    nn_idx[(int64_t)pair * n_pad_items + it] = t.i1;
-    best[(int64_t)pair * n_pad_items + it] = t.b1;
-    uncertain[(int64_t)pair * n_pad_items + it] = (force_uncertain || !(t.b1 - t.b2 > kBand)) ? 1 : 0;
+    const int win = parts > 0 ? partial_index(v.is_row, pbest, b1) : -1;
+    if (v.is_row) idx0[(int64_t)pair * n0_pad + v.self] = win;
+    else idx1[(int64_t)pair * n1_pad + v.self] = win;
+    const bool uncertain = (force_rows && v.is_row) || !(b1 - b2 > pair_band(stats, pair));
+    if (uncertain && parts > 0) {
+        const int slot = atomicAdd(rescan_count, 1);
+        rescan_list[2 * (int64_t)slot] = pair;
+        rescan_list[2 * (int64_t)slot + 1] = it;
+    }
 }
 
 // The reference's distance, bit for bit: double accumulation in index order, narrowed to float,
@@ -438,19 +509,114 @@ __device__ __forceinline__ float distance_from_dot(double acc)
     return sqrtf(2.0f - 2.0f * s);
 }
 
-// Certain items: exact distance of the winner.  Uncertain items: appended to the rescan list and
-// their packed (distance, index) key reset.  One wave per 64 items over both directions:
-// item < n0_pad -> row, else column.
+// Exact re-decision of the listed rows/columns, one wave per item.  Lanes first look at one
+// 64-candidate chunk each: a chunk whose best approximate score lies more than the band below
+// the item's best cannot hold the exact first minimum; a chunk whose SECOND best lies below the
+// band contributes only its best entry; any other chunk is scanned whole.  Exact distances come
+// from staged panels; the wave minimum of the packed (distance bits, index) keys is the
+// reference's first minimum (non-negative floats order like their bit patterns).
 template <bool MASKED>
 __global__ void __launch_bounds__(64)
-exact_winner_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+rescan_items_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
                     const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
                     const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
-                    const int *__restrict__ idx0, const int *__restrict__ idx1,
-                    const unsigned char *__restrict__ unc0, const unsigned char *__restrict__ unc1,
-                    float *__restrict__ dist0, float *__restrict__ dist1,
-                    int *__restrict__ rescan_list, int *__restrict__ rescan_count,
-                    unsigned long long *__restrict__ keys)
+                    const int *__restrict__ rescan_list, const int *__restrict__ rescan_count,
+                    const float2 *__restrict__ row_part, const float2 *__restrict__ col_part,
+                    const unsigned *__restrict__ stats, int *__restrict__ idx0,
+                    int *__restrict__ idx1)
+{
+    __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
+    __shared__ __attribute__((aligned(16))) float tA[kD];
+    __shared__ const float *pA[1];
+    __shared__ const float *pB[64];
+    const int lane = threadIdx.x;
+    const int count = *rescan_count;
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int pair = rescan_list[2 * (int64_t)w], it = rescan_list[2 * (int64_t)w + 1];
+        const PairDims dm = dims[pair];
+        const ItemView v = item_view(pair, it, dm, n0_pad, n1_pad, row_part, col_part);
+        const int parts = (v.n_cand + kSub - 1) / kSub;
+        const float band = pair_band(stats, pair);
+        const float *self_row = v.is_row ? d0 + ((int64_t)pair * n0_pad + v.self) * kD
+                                         : d1 + ((int64_t)pair * n1_pad + v.self) * kD;
+        const float *other_base = v.is_row ? d1 + (int64_t)pair * n1_pad * kD : d0 + (int64_t)pair * n0_pad * kD;
+        const int2 self_xy = MASKED ? (v.is_row ? xy0[(int64_t)pair * n0_pad + v.self] : xy1[(int64_t)pair * n1_pad + v.self])
+                                    : make_int2(0, 0);
+        const int2 *other_xy = v.is_row ? xy1 + (int64_t)pair * n1_pad : xy0 + (int64_t)pair * n0_pad;
+        // the item's best approximate score
+        float item_best = kNegInf;
+        for (int p = lane; p < parts; p += 64) item_best = fmaxf(item_best, v.part[p * v.stride].x);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) item_best = fmaxf(item_best, __shfl_xor(item_best, off, 64));
+
+        unsigned long long key = ~0ull;
+        // exact distance of candidate `c` for this lane given the finished dot
+        auto candidate_key = [&](int c, double acc) -> unsigned long long {
+            float d = distance_from_dot(acc);
+            if (MASKED) {
+                const int2 o = other_xy[c];
+                if (v.is_row ? stereo_masked(self_xy, o) : stereo_masked(o, self_xy)) d = 1.0f;
+            }
+            return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)c;
+        };
+        for (int pbase = 0; pbase < parts; pbase += 64) {
+            const int p = pbase + lane;
+            float2 q = make_float2(kNegInf, kNegInf);
+            if (p < parts) q = v.part[p * v.stride];
+            const bool in_band = p < parts && item_best - q.x <= band;
+            const bool whole = in_band && item_best - q.y <= band;
+            const bool single = in_band && !whole;
+            if (__ballot(single)) {
+                const int c = single ? partial_index(v.is_row, p, q.x) : 0;
+                __syncthreads();
+                if (lane == 0) pA[0] = self_row;
+                pB[lane] = other_base + (int64_t)c * kD;
+                __syncthreads();
+                const double acc = panel_dot64<true>(pA, pB, tA, tB, lane);
+                if (single) {
+                    const unsigned long long k = candidate_key(c, acc);
+                    key = k < key ? k : key;
+                }
+            }
+            unsigned long long todo = __ballot(whole);
+            while (todo) {
+                const int pl = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int c = (pbase + pl) * kSub + lane;
+                const int cc = c < v.n_cand ? c : 0;
+                __syncthreads();
+                if (lane == 0) pA[0] = self_row;
+                pB[lane] = other_base + (int64_t)cc * kD;
+                __syncthreads();
+                const double acc = panel_dot64<true>(pA, pB, tA, tB, lane);
+                if (c < v.n_cand) {
+                    const unsigned long long k = candidate_key(c, acc);
+                    key = k < key ? k : key;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o < key ? o : key;
+        }
+        if (lane == 0) {
+            const int win = (int)(key & 0xffffffffu);
+            if (v.is_row) idx0[(int64_t)pair * n0_pad + v.self] = win;
+            else idx1[(int64_t)pair * n1_pad + v.self] = win;
+        }
+    }
+}
+
+// Exact distance of every mutual row (idx1[idx0[i]] == i); other rows get +huge and never
+// reach the output.  One wave per 64 rows.
+template <bool MASKED>
+__global__ void __launch_bounds__(64)
+mutual_distance_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+                       const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
+                       const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
+                       const int *__restrict__ idx0, const int *__restrict__ idx1,
+                       float *__restrict__ dist0)
 {
     __shared__ __attribute__((aligned(16))) float tA[64 * kPanelStride];
     __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
@@ -458,110 +624,23 @@ exact_winner_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
     __shared__ const float *pB[64];
     const int pair = blockIdx.y;
     const int lane = threadIdx.x;
-    const int it = blockIdx.x * 64 + lane;
+    const int i = blockIdx.x * 64 + lane;
     const int n0 = dims[pair].n0, n1 = dims[pair].n1;
-    int i = 0, j = 0;
-    bool valid = false, unc = false;
-    if (it < n0_pad) {
-        if (it < n0) { valid = true; i = it; j = idx0[(int64_t)pair * n0_pad + it]; unc = unc0[(int64_t)pair * n0_pad + it]; }
-    } else if (it - n0_pad < n1) {
-        const int c = it - n0_pad;
-        valid = true; j = c; i = idx1[(int64_t)pair * n1_pad + c]; unc = unc1[(int64_t)pair * n1_pad + c];
-    }
-    bool masked = false;
-    if (MASKED && valid && !unc)
-        masked = stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j]);
-    pA[lane] = d0 + ((int64_t)pair * n0_pad + i) * kD;
-    pB[lane] = d1 + ((int64_t)pair * n1_pad + j) * kD;
-    __syncthreads();
-    const double acc = panel_dot64<false>(pA, pB, tA, tB, lane);
-    if (!valid) return;
-    if (unc) {
-        const int slot = atomicAdd(rescan_count, 1);
-        rescan_list[2 * (int64_t)slot] = pair;
-        rescan_list[2 * (int64_t)slot + 1] = it;
-        keys[(int64_t)pair * (n0_pad + n1_pad) + it] = ~0ull;
+    if (blockIdx.x * 64 >= n0) return;
+    int j = -1;
+    if (i < n0) j = idx0[(int64_t)pair * n0_pad + i];
+    const bool mutual = j >= 0 && j < n1 && idx1[(int64_t)pair * n1_pad + j] == i;
+    if (!__ballot(mutual)) {
+        if (i < n0) dist0[(int64_t)pair * n0_pad + i] = 3.0e38f;
         return;
     }
-    const float d = masked ? 1.0f : distance_from_dot(acc);
-    if (it < n0_pad) dist0[(int64_t)pair * n0_pad + it] = d;
-    else dist1[(int64_t)pair * n1_pad + it - n0_pad] = d;
-}
-
-// Exact re-decision of the listed rows/columns, 64 candidates per wave task: exact distances
-// from staged panels, wave minimum with lowest-index tie-break, one 64-bit atomic min of the
-// packed (distance bits, index) key per task (non-negative floats order like their bit patterns).
-template <bool MASKED>
-__global__ void __launch_bounds__(64)
-rescan_chunk_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
-                    const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
-                    const int2 *__restrict__ xy1, int n0_pad, int n1_pad, int chunks,
-                    const int *__restrict__ rescan_list, const int *__restrict__ rescan_count,
-                    const float *__restrict__ row_b1, const float *__restrict__ col_b1,
-                    const float *__restrict__ best0, const float *__restrict__ best1,
-                    unsigned long long *__restrict__ keys)
-{
-    __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
-    __shared__ __attribute__((aligned(16))) float tA[kD];
-    __shared__ const float *pA[1];
-    __shared__ const float *pB[64];
-    const int lane = threadIdx.x;
-    const int64_t n_tasks = (int64_t)(*rescan_count) * chunks;
-    for (int64_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
-        const int w = (int)(t / chunks), chunk = (int)(t % chunks);
-        const int pair = rescan_list[2 * (int64_t)w], it = rescan_list[2 * (int64_t)w + 1];
-        const int n0 = dims[pair].n0, n1 = dims[pair].n1;
-        const bool is_row = it < n0_pad;
-        const int self = is_row ? it : it - n0_pad;
-        const int n_cand = is_row ? n1 : n0;
-        if (chunk * 64 >= n_cand) continue;                          // uniform per workgroup
-        // a chunk whose best approximate score is more than the band below the item's best
-        // cannot contain the exact first minimum
-        const float chunk_best = is_row ? row_b1[((int64_t)pair * (n1_pad / kSub) + chunk) * n0_pad + self]
-                                        : col_b1[((int64_t)pair * (n0_pad / kSub) + chunk) * n1_pad + self];
-        const float item_best = is_row ? best0[(int64_t)pair * n0_pad + self] : best1[(int64_t)pair * n1_pad + self];
-        if (!(item_best - chunk_best <= kBand)) continue;
-        const int c = chunk * 64 + lane;
-        __syncthreads();
-        if (lane == 0)
-            pA[0] = is_row ? d0 + ((int64_t)pair * n0_pad + self) * kD : d1 + ((int64_t)pair * n1_pad + self) * kD;
-        pB[lane] = is_row ? d1 + ((int64_t)pair * n1_pad + c) * kD : d0 + ((int64_t)pair * n0_pad + c) * kD;
-        __syncthreads();
-        const double acc = panel_dot64<true>(pA, pB, tA, tB, lane);
-        float d = 3.0e38f;
-        if (c < n_cand) {
-            d = distance_from_dot(acc);
-            if (MASKED) {
-                const int i = is_row ? self : c, j = is_row ? c : self;
-                if (stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j])) d = 1.0f;
-            }
-        }
-        unsigned long long key = c < n_cand ? ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)c : ~0ull;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(key, off, 64);
-            key = o < key ? o : key;
-        }
-        if (lane == 0) atomicMin(&keys[(int64_t)pair * (n0_pad + n1_pad) + it], key);
-    }
-}
-
-// Unpack the keys of the re-decided items into the index / distance arrays.
-__global__ void __launch_bounds__(256)
-unpack_kernel(int n0_pad, int n1_pad, const int *__restrict__ rescan_list,
-              const int *__restrict__ rescan_count, const unsigned long long *__restrict__ keys,
-              int *__restrict__ idx0, int *__restrict__ idx1, float *__restrict__ dist0,
-              float *__restrict__ dist1)
-{
-    const int count = *rescan_count;
-    for (int w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
-        const int pair = rescan_list[2 * (int64_t)w], it = rescan_list[2 * (int64_t)w + 1];
-        const unsigned long long key = keys[(int64_t)pair * (n0_pad + n1_pad) + it];
-        const int idx = (int)(key & 0xffffffffu);
-        const float d = __uint_as_float((unsigned)(key >> 32));
-        if (it < n0_pad) { idx0[(int64_t)pair * n0_pad + it] = idx; dist0[(int64_t)pair * n0_pad + it] = d; }
-        else { idx1[(int64_t)pair * n1_pad + it - n0_pad] = idx; dist1[(int64_t)pair * n1_pad + it - n0_pad] = d; }
-    }
+    bool masked = false;
+    if (MASKED && mutual) masked = stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j]);
+    pA[lane] = d0 + ((int64_t)pair * n0_pad + (mutual ? i : 0)) * kD;
+    pB[lane] = d1 + ((int64_t)pair * n1_pad + (mutual ? j : 0)) * kD;
+    __syncthreads();
+    const double acc = panel_dot64<false>(pA, pB, tA, tB, lane);
+    if (i < n0) dist0[(int64_t)pair * n0_pad + i] = !mutual ? 3.0e38f : masked ? 1.0f : distance_from_dot(acc);
 }
 
 // Ratio-test mode only: exact scan of one whole row or column per wave (first minimum) that
@@ -642,7 +721,7 @@ compact_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
         if (i < n0) {
             j = idx0[(int64_t)pair * n0_pad + i];
             d = dist0[(int64_t)pair * n0_pad + i];
-            keep = idx1[(int64_t)pair * n1_pad + j] == i && d < nn_thresh;
+            keep = j >= 0 && idx1[(int64_t)pair * n1_pad + j] == i && d < nn_thresh;
             if (keep && ratio < 1.0f) keep = d < ratio * second0[(int64_t)pair * n0_pad + i];
         }
         const unsigned long long m = __ballot(keep);
@@ -682,13 +761,13 @@ struct vs_matcher {
     bool ran = false;
     hipEvent_t *prof_ev = nullptr;   // when set: 6 events recorded around vs_matcher_run's stages
     DevBuf<float> d0, d1;
-    DevBuf<_Float16> a_hi, a_lo, b_hi, b_lo;
+    DevBuf<_Float16> a16, b16;
+    DevBuf<unsigned> stats;          // 4 per pair, see pair_band()
     DevBuf<int2> xy0, xy1;
     DevBuf<PairDims> dims;
-    DevBuf<float> row_b1, row_b2, col_b1, col_b2, dist0, dist1, second0, out_d, best0, best1;
-    DevBuf<int> row_i1, col_i1, idx0, idx1, rescan_list, rescan_count, out_i, out_j, out_n;
-    DevBuf<unsigned char> unc0, unc1;
-    DevBuf<unsigned long long> keys;
+    DevBuf<float2> row_part, col_part;   // (best, second) packed scores per item and 64-chunk
+    DevBuf<float> dist0, dist1, second0, out_d;
+    DevBuf<int> idx0, idx1, rescan_list, rescan_count, out_i, out_j, out_n;
 };
 
 extern "C" {
@@ -710,15 +789,13 @@ int vs_matcher_create(vs_matcher_handle *out, int32_t max_pairs, int32_t max_n0,
     int rc = VS_OK;
     auto A = [&](int r) { if (rc == VS_OK) rc = r; };
     A(m->d0.alloc(P * r0 * kD)); A(m->d1.alloc(P * r1 * kD));
-    A(m->a_hi.alloc(P * r0 * kD)); A(m->a_lo.alloc(P * r0 * kD));
-    A(m->b_hi.alloc(P * r1 * kD)); A(m->b_lo.alloc(P * r1 * kD));
+    A(m->a16.alloc(P * r0 * kD)); A(m->b16.alloc(P * r1 * kD)); A(m->stats.alloc(4 * P));
     A(m->xy0.alloc(P * r0)); A(m->xy1.alloc(P * r1)); A(m->dims.alloc(P));
     const size_t rp = P * (r1 / kSub) * r0, cp = P * (r0 / kSub) * r1;
-    A(m->row_b1.alloc(rp)); A(m->row_b2.alloc(rp)); A(m->row_i1.alloc(rp));
-    A(m->col_b1.alloc(cp)); A(m->col_b2.alloc(cp)); A(m->col_i1.alloc(cp));
+    A(m->row_part.alloc(rp)); A(m->col_part.alloc(cp));
     A(m->idx0.alloc(P * r0)); A(m->idx1.alloc(P * r1)); A(m->dist0.alloc(P * r0)); A(m->dist1.alloc(P * r1));
-    A(m->second0.alloc(P * r0)); A(m->best0.alloc(P * r0)); A(m->best1.alloc(P * r1)); A(m->unc0.alloc(P * r0)); A(m->unc1.alloc(P * r1));
-    A(m->rescan_list.alloc(2 * P * (r0 + r1))); A(m->rescan_count.alloc(4)); A(m->keys.alloc(P * (r0 + r1)));
+    A(m->second0.alloc(P * r0));
+    A(m->rescan_list.alloc(2 * P * (r0 + r1))); A(m->rescan_count.alloc(4));
     A(m->out_i.alloc(P * r0)); A(m->out_j.alloc(P * r0)); A(m->out_d.alloc(P * r0)); A(m->out_n.alloc(P));
     if (rc != VS_OK) { delete m; return rc; }
     m->h_dims.assign(P, PairDims{ 0, 0 });
@@ -758,10 +835,11 @@ int vs_matcher_set_pair(vs_matcher_handle m, int32_t pair, const float *desc0, i
         if (n1) VS_HIP(hipMemcpyAsync(m->xy1.p + (size_t)pair * m->n1_pad, xy1, (size_t)n1 * sizeof(int2), hipMemcpyDefault, s));
     }
     const size_t e0 = (size_t)m->n0_pad * kD, e1 = (size_t)m->n1_pad * kD;
-    hipLaunchKernelGGL(split_kernel, dim3(div_up((int64_t)e0 / 4, 256)), dim3(256), 0, s, g0, n0, m->n0_pad,
-                       m->a_hi.p + (size_t)pair * e0, m->a_lo.p + (size_t)pair * e0);
-    hipLaunchKernelGGL(split_kernel, dim3(div_up((int64_t)e1 / 4, 256)), dim3(256), 0, s, g1, n1, m->n1_pad,
-                       m->b_hi.p + (size_t)pair * e1, m->b_lo.p + (size_t)pair * e1);
+    VS_HIP(hipMemsetAsync(m->stats.p + 4 * (size_t)pair, 0, 4 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(split_kernel, dim3(div_up(m->n0_pad, kSplitRows)), dim3(256), 0, s, g0, n0, m->n0_pad,
+                       m->a16.p + (size_t)pair * e0, m->stats.p + 4 * (size_t)pair);
+    hipLaunchKernelGGL(split_kernel, dim3(div_up(m->n1_pad, kSplitRows)), dim3(256), 0, s, g1, n1, m->n1_pad,
+                       m->b16.p + (size_t)pair * e1, m->stats.p + 4 * (size_t)pair + 2);
     VS_TRY(launch_ok("split_kernel"));
     m->h_dims[pair] = PairDims{ n0, n1 };
     m->h_masked[pair] = xy0 != nullptr;
@@ -781,37 +859,29 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
     hipStream_t s = m->stream;
     auto mark = [&](int i) { if (m->prof_ev) (void)hipEventRecord(m->prof_ev[i], s); };
     const int r0 = m->n0_pad, r1 = m->n1_pad;
-    const int tiles = (r0 / kBM) * (r1 / kBN);
+    // column tiles per workgroup: whole rows of tiles when that still gives every CU several
+    // workgroups, otherwise split the tile rows
+    const int ntr = r0 / kBM, ntc = r1 / kBN;
+    const int want_splits = std::min(ntc, std::max(1, div_up(2048, n_pairs * ntr)));
+    const int tiles_per_wg = div_up(ntc, want_splits);
+    const int splits = div_up(ntc, tiles_per_wg);
     mark(0);
-    const dim3 grid(tiles, 1, n_pairs);
+    const dim3 grid(n_pairs * ntr * splits);
     if (masked)
-        hipLaunchKernelGGL(dot_top2_kernel<true>, grid, dim3(256), 0, s, m->a_hi.p, m->a_lo.p, m->b_hi.p, m->b_lo.p,
-                           m->dims.p, m->xy0.p, m->xy1.p, r0, r1, m->row_b1.p, m->row_i1.p, m->row_b2.p,
-                           m->col_b1.p, m->col_i1.p, m->col_b2.p);
+        hipLaunchKernelGGL(dot_top2_kernel<true>, grid, dim3(256), 0, s, m->a16.p, m->b16.p, m->dims.p, m->xy0.p,
+                           m->xy1.p, r0, r1, tiles_per_wg, m->row_part.p, m->col_part.p);
     else
-        hipLaunchKernelGGL(dot_top2_kernel<false>, grid, dim3(256), 0, s, m->a_hi.p, m->a_lo.p, m->b_hi.p, m->b_lo.p,
-                           m->dims.p, m->xy0.p, m->xy1.p, r0, r1, m->row_b1.p, m->row_i1.p, m->row_b2.p,
-                           m->col_b1.p, m->col_i1.p, m->col_b2.p);
+        hipLaunchKernelGGL(dot_top2_kernel<false>, grid, dim3(256), 0, s, m->a16.p, m->b16.p, m->dims.p, m->xy0.p,
+                           m->xy1.p, r0, r1, tiles_per_wg, m->row_part.p, m->col_part.p);
     VS_TRY(launch_ok("dot_top2_kernel"));
     mark(1);
     const int force = ratio < 1.0f ? 1 : 0;   // the ratio test needs every row's exact second best
-    hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0, 256), n_pairs), dim3(256), 0, s, m->dims.p, r0, r1 / kSub, 0,
-                       m->row_b1.p, m->row_i1.p, m->row_b2.p, m->idx0.p, m->unc0.p, m->best0.p, force);
-    hipLaunchKernelGGL(merge_kernel, dim3(div_up(r1, 256), n_pairs), dim3(256), 0, s, m->dims.p, r1, r0 / kSub, 1,
-                       m->col_b1.p, m->col_i1.p, m->col_b2.p, m->idx1.p, m->unc1.p, m->best1.p, 0);
+    VS_HIP(hipMemsetAsync(m->rescan_count.p, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0 + r1, 256), n_pairs), dim3(256), 0, s, m->dims.p, r0, r1,
+                       m->row_part.p, m->col_part.p, m->stats.p, m->idx0.p, m->idx1.p, m->rescan_list.p,
+                       m->rescan_count.p, force);
     VS_TRY(launch_ok("merge_kernel"));
     mark(2);
-    VS_HIP(hipMemsetAsync(m->rescan_count.p, 0, 4 * sizeof(int), s));
-    const dim3 egrid(div_up(r0 + r1, 64), n_pairs);
-    const int chunks = std::max(r0, r1) / 64;
-    if (masked)
-        hipLaunchKernelGGL(exact_winner_kernel<true>, egrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
-                           m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->unc0.p, m->unc1.p, m->dist0.p, m->dist1.p,
-                           m->rescan_list.p, m->rescan_count.p, m->keys.p);
-    else
-        hipLaunchKernelGGL(exact_winner_kernel<false>, egrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
-                           m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->unc0.p, m->unc1.p, m->dist0.p, m->dist1.p,
-                           m->rescan_list.p, m->rescan_count.p, m->keys.p);
     if (force) {
         // ratio test: every row needs its exact second-best distance -> whole-row scans
         if (masked)
@@ -823,16 +893,20 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
                                m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->idx0.p, m->idx1.p,
                                m->dist0.p, m->dist1.p, m->second0.p);
     } else {
-        if (masked)
-            hipLaunchKernelGGL(rescan_chunk_kernel<true>, dim3(16384), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
-                               m->xy0.p, m->xy1.p, r0, r1, chunks, m->rescan_list.p, m->rescan_count.p, m->row_b1.p, m->col_b1.p,
-                               m->best0.p, m->best1.p, m->keys.p);
-        else
-            hipLaunchKernelGGL(rescan_chunk_kernel<false>, dim3(16384), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
-                               m->xy0.p, m->xy1.p, r0, r1, chunks, m->rescan_list.p, m->rescan_count.p, m->row_b1.p, m->col_b1.p,
-                               m->best0.p, m->best1.p, m->keys.p);
-        hipLaunchKernelGGL(unpack_kernel, dim3(64), dim3(256), 0, s, r0, r1, m->rescan_list.p, m->rescan_count.p,
-                           m->keys.p, m->idx0.p, m->idx1.p, m->dist0.p, m->dist1.p);
+        const dim3 dgrid(div_up(r0, 64), n_pairs);
+        if (masked) {
+            hipLaunchKernelGGL(rescan_items_kernel<true>, dim3(8192), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
+                               m->xy0.p, m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->row_part.p,
+                               m->col_part.p, m->stats.p, m->idx0.p, m->idx1.p);
+            hipLaunchKernelGGL(mutual_distance_kernel<true>, dgrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
+                               m->xy0.p, m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->dist0.p);
+        } else {
+            hipLaunchKernelGGL(rescan_items_kernel<false>, dim3(8192), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
+                               m->xy0.p, m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->row_part.p,
+                               m->col_part.p, m->stats.p, m->idx0.p, m->idx1.p);
+            hipLaunchKernelGGL(mutual_distance_kernel<false>, dgrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
+                               m->xy0.p, m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->dist0.p);
+        }
     }
     VS_TRY(launch_ok("exact kernels"));
     mark(3);

@@ -30,7 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kD = VS_DESC_DIM;        // 256
 constexpr int kBM = 128, kBN = 128;    // workgroup tile
-constexpr int kBK = 64;                // halfs per K-step
+constexpr int kBK = 64;                // halfs per K-step (one ring stage)
+constexpr int kRing = 2;               // LDS ring stages (kRing - 1 K-steps of lookahead)
 constexpr int kSub = 64;               // rows/cols covered by one wave = granularity of partials
 constexpr float kScale = 256.0f;       // descriptor prescale (2^8), dot prescale 2^16
 constexpr float kDotScale = 65536.0f;
@@ -126,14 +127,23 @@ struct PairDims {
     int n0, n1;
 };
 
-// LDS image of one streamed desc1 K-step: kBN rows (columns of the score tile) x kBK halfs,
-// unpadded 128-byte rows whose eight 16-byte chunks are XOR-swizzled with (row >> 1) & 7, which
-// makes the ds_read_b128 fragment reads conflict-free.  The image is filled by LDS-DMA
-// (global_load_lds_dwordx4: destination = wave-uniform base + 16 * lane), so the swizzle is applied
-// to the per-lane SOURCE address and again to the read address.
-constexpr int kStageBytes = kBN * kBK * 2;              // 16 KiB
+// LDS image of one streamed desc1 K-step: kBN rows (columns of the score tile) x kBK halfs in
+// unpadded rows whose 16-byte chunks are XOR-swizzled with the row number so that the
+// ds_read_b128 fragment reads are conflict-free (rows sharing a 256-byte bank line get different
+// chunk slots).  The image is filled by LDS-DMA (global_load_lds_dwordx4: destination =
+// wave-uniform base + 16 * lane), so the swizzle is applied to the per-lane SOURCE address and
+// again to the read address.
+constexpr int kStageBytes = kBN * kBK * 2;
+constexpr int kChunksPerRow = kBK / 8;                  // 16-byte chunks per image row
+constexpr int kRowsPerDma = 64 / kChunksPerRow;         // image rows per DMA wave-instruction
+constexpr int kDmaPerWave = 32 / kRowsPerDma;           // DMA instructions per wave and stage
+constexpr int kSwzShift = kBK == 64 ? 1 : 2;            // log2(rows per 256-byte bank line)
+constexpr int kInflight = (kRing - 2) * kDmaPerWave;    // DMAs allowed in flight behind stage s
+static_assert(kBK == 32 || kBK == 64, "swizzle is written for 64- and 128-byte image rows");
+__device__ __forceinline__ int stage_swizzle(int row) { return (row >> kSwzShift) & (kChunksPerRow - 1); }
 constexpr int kTS = 68;                                 // transpose row stride in floats
-constexpr int kDotLds = 2 * kStageBytes + 4 * 32 * kTS * 4;
+constexpr int kDotLds = kRing * kStageBytes + 4 * 32 * kTS * 4;
+static_assert(2 * kDotLds <= 160 * 1024, "two workgroups per CU");
 
 // One workgroup = one band: kBM rows of desc0 of one frame pair against `tiles_per_wg` consecutive
 // kBN-column tiles of desc1.  4 waves, each a 64 x 64 sub-tile as 2 x 2 MFMA 32x32x16 f16 tiles.
@@ -186,39 +196,37 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
                 af[m][ks] = *reinterpret_cast<const half8 *>(gA + (int64_t)m * 32 * kD + ks * 16);
     }
 
-    // LDS-DMA map: a stage is 16 wave-instructions of 8 rows x 128 B; wave w fills rows
-    // [32 w, 32 w + 32).  Lane l writes chunk slot (l & 7) of row 8 q + (l >> 3) and therefore
-    // fetches source chunk (l & 7) ^ ((row >> 1) & 7).
-    int src_off[4];
+    // LDS-DMA map: wave w fills image rows [32 w, 32 w + 32) of a stage with kDmaPerWave
+    // instructions of kRowsPerDma rows.  Lane l writes chunk slot l % kChunksPerRow of row
+    // l / kChunksPerRow and therefore fetches source chunk slot ^ swizzle(row).
+    int src_off[kDmaPerWave];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int row = wave * 32 + q * 8 + (lane >> 3);
-        src_off[q] = row * kD + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    for (int q = 0; q < kDmaPerWave; q++) {
+        const int row = wave * 32 + q * kRowsPerDma + lane / kChunksPerRow;
+        src_off[q] = row * kD + (((lane % kChunksPerRow) ^ stage_swizzle(row)) * 8);
     }
     const _Float16 *gB = b16 + (int64_t)pair * n1_pad * kD;
-    const int n_stages = (c_end - c_begin) * (kD / kBK);
+    constexpr int kStepsPerTile = kD / kBK;
+    const int n_stages = (c_end - c_begin) * kStepsPerTile;
 #define VS_ISSUE_STAGE(s_)                                                                     \
     do {                                                                                       \
         const int st_ = (s_);                                                                  \
-        const _Float16 *g_ = gB + (int64_t)(c_begin + st_ / (kD / kBK)) * kBN * kD + (st_ % (kD / kBK)) * kBK; \
-        unsigned char *l_ = smem + (st_ & 1) * kStageBytes + wave * 4096;                      \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[0]), \
-                                         (__attribute__((address_space(3))) void *)(l_), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[1]), \
-                                         (__attribute__((address_space(3))) void *)(l_ + 1024), 16, 0, 0);  \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[2]), \
-                                         (__attribute__((address_space(3))) void *)(l_ + 2048), 16, 0, 0);  \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[3]), \
-                                         (__attribute__((address_space(3))) void *)(l_ + 3072), 16, 0, 0);  \
+        const _Float16 *g_ = gB + (int64_t)(c_begin + st_ / kStepsPerTile) * kBN * kD + (st_ % kStepsPerTile) * kBK; \
+        unsigned char *l_ = smem + (st_ % kRing) * kStageBytes + wave * (32 * kBK * 2);        \
+        _Pragma("unroll") for (int q_ = 0; q_ < kDmaPerWave; q_++)                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[q_]), \
+                                             (__attribute__((address_space(3))) void *)(l_ + q_ * 1024), 16, 0, 0); \
     } while (0)
 
-    // fragment read offsets inside a stage: column wc*64 + n*32 + l31, chunk (2 ks + half) ^ swz
-    const int swz = (l31 >> 1) & 7;
+    // fragment read offsets inside a stage: image row wc*64 + n*32 + l31, chunk (2 ks + half) ^ swz
+    const int swz = stage_swizzle(l31);
     const int frag_row = (wc * 64 + l31) * (kBK * 2);
 
-    float *sT = reinterpret_cast<float *>(smem + 2 * kStageBytes) + wave * (32 * kTS);
+    float *sT = reinterpret_cast<float *>(smem + kRing * kStageBytes) + wave * (32 * kTS);
 
-    VS_ISSUE_STAGE(0);
+#pragma unroll
+    for (int st = 0; st < kRing - 1; st++)
+        if (st < n_stages) VS_ISSUE_STAGE(st);
     for (int tc = c_begin; tc < c_end; tc++) {
     const int j0 = tc * kBN;
     f32x16 acc[2][2];
@@ -230,15 +238,19 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
 #pragma unroll
-    for (int kt = 0; kt < kD / kBK; kt++) {
-        const int s = (tc - c_begin) * (kD / kBK) + kt;
-        // this wave's share of stage s has landed; after the barrier every wave's has, and every
-        // wave has finished reading the other buffer (stage s - 1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int kt = 0; kt < kStepsPerTile; kt++) {
+        const int s = (tc - c_begin) * kStepsPerTile + kt;
+        // Wait until this wave's share of stage s has landed; after the barrier every wave's has,
+        // and every wave has finished reading ring slot (s - 1) % kRing, which is refilled next.
+        // Loads return in issue order, so allowing the DMAs of the kRing - 2 younger stages to
+        // stay in flight retires stage s; the first step of a tile (the epilogue's stores sit
+        // between the DMAs) and the tail of the band (fewer younger stages exist) drain fully.
+        if (kt == 0 || s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInflight) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < n_stages) VS_ISSUE_STAGE(s + 1);
-        const unsigned char *buf = smem + (s & 1) * kStageBytes + frag_row;
+        if (s + kRing - 1 < n_stages) VS_ISSUE_STAGE(s + kRing - 1);
+        const unsigned char *buf = smem + (s % kRing) * kStageBytes + frag_row;
 #pragma unroll
         for (int ks = 0; ks < kBK / 16; ks++) {
             half8 bf[2];

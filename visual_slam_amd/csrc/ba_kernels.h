@@ -474,7 +474,7 @@ __device__ __forceinline__ void load_rec(const real *__restrict__ lmrec, int j, 
 // straight into the reduce buffer, otherwise a per-item partial is written and finalize_kernel
 // adds the partials in item order.
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES *kWave)
+__global__ void __launch_bounds__(WAVES *kWave) __attribute__((amdgpu_waves_per_eu(WAVES == 1 ? 3 : 2, WAVES == 1 ? 3 : 2)))
 blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
               const CamData *__restrict__ cams, const real *__restrict__ lmrec,
               const int *__restrict__ cpt, const real *__restrict__ cuv,

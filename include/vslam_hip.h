@@ -200,6 +200,43 @@ int vs_match_stereo(const float *desc0, const int32_t *xy0, int32_t n0, const fl
                     const int32_t *xy1, int32_t n1, float nn_thresh, float ratio, int32_t *out_i,
                     int32_t *out_j, float *out_d, int32_t *out_n);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-frame tracking helpers beside the matcher.  Poses are transform::Rigid3f as 7 floats:
+ * translation x, y, z then rotation quaternion w, x, y, z (src/transform/rigid_transform.h:101-103);
+ * K4 = fx, fy, cx, cy (config/config.yaml:12-16).  Pixel coordinates are cv::Point (n x 2 int32).
+ * Host or device pointers; every call blocks until its results are in the output arrays.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Tracking::reprojection (src/core/tracking.cc:70-78) for n world points: float pinhole
+ * projection of Tcw * Pw along +Y, truncated to integer pixels. */
+int vs_reproject_points(const float *pose, const float *K4, const float *xyz, int32_t n,
+                        int32_t *xy);
+
+/* Tracking::searchProjection (src/core/tracking.cc:453-496): every tracked point i (world point
+ * + descriptor), in index order, takes the keypoint j with the smallest descriptor distance
+ * among those not yet claimed and within `radius` pixels of its reprojection (first minimum in
+ * j order), if that distance is < accept (0.8 in the reference) and the reprojection lies inside
+ * [0, 2cx] x [0, 2cy].  claimed (n_keys bytes, in/out) marks keypoints that own a tracked point
+ * (Frame::tps() != nullptr); tracks[i] = j or -1. */
+int vs_search_projection(const float *pose, const float *K4, const float *tp_xyz,
+                         const float *tp_desc, int32_t n_tp, const int32_t *key_xy,
+                         const float *key_desc, int32_t n_keys, float radius, double accept,
+                         uint8_t *claimed, int32_t *tracks);
+
+/* Tracking::removeOutlier for one frame (src/core/tracking.cc:357-372): tracks[i] = -1 where the
+ * tracked keypoint and the integer reprojection are more than max_dist (20) pixels apart. */
+int vs_remove_outliers(const float *pose, const float *K4, const float *tp_xyz, int32_t n_tp,
+                       const int32_t *key_xy, int32_t n_keys, double max_dist, int32_t *tracks,
+                       int32_t *n_removed);
+
+/* Frame::computePoint3d (src/core/frame.cc:45-86) for all n0 left keypoints: nearest right
+ * keypoint among those with |yl - yr| <= 20 and xl >= xr, disparity > 1, depth = bf / disparity,
+ * back-projection through inv(K) and the inverse pose.  good[i] = 1 and xyz[3i..3i+2] = Pw where
+ * the reference returns true; minloc (optional) = chosen right keypoint or -1. */
+int vs_compute_points3d(const float *desc0, const int32_t *xy0, int32_t n0, const float *desc1,
+                        const int32_t *xy1, int32_t n1, const float *K4, float baseline_fx,
+                        const float *pose, uint8_t *good, float *xyz, int32_t *minloc);
+
 #ifdef __cplusplus
 }
 #endif

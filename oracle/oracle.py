@@ -224,3 +224,49 @@ def search_projection(reproj_xy, tp_desc, key_xy, key_desc, width2, height2, rad
                                C.c_float(radius), C.c_double(accept),
                                claimed.ctypes.data_as(c_bp), _i(tracks))
     return tracks, claimed
+
+
+# ---- per-frame tracking helpers (track_oracle.c) -------------------------------------------
+
+def reproject_points(pose, K4f, xyz):
+    pose, K4f, xyz = _f32(pose), _f32(K4f), _f32(xyz).reshape(-1, 3)
+    out = np.zeros((len(xyz), 2), np.int32)
+    lib().vo_reproject_points(_f(pose), _f(K4f), _f(xyz), len(xyz), _i(out))
+    return out
+
+
+def remove_outliers(pose, K4f, xyz, key_xy, tracks, max_dist=20.0):
+    pose, K4f, xyz = _f32(pose), _f32(K4f), _f32(xyz).reshape(-1, 3)
+    key_xy, tracks = _i32(key_xy), _i32(tracks).copy()
+    lib().vo_remove_outliers.restype = C.c_int
+    n = lib().vo_remove_outliers(_f(pose), _f(K4f), _f(xyz), len(xyz), _i(key_xy),
+                                 C.c_double(max_dist), _i(tracks))
+    return tracks, n
+
+
+def inv_k3(K4f):
+    out = np.zeros(9, np.float32)
+    lib().vo_inv_k3(_f(_f32(K4f)), _f(out))
+    return out.reshape(3, 3)
+
+
+def rigid_apply(pose, p):
+    out = np.zeros(3, np.float32)
+    lib().vo_rigid_apply_f(_f(_f32(pose)), _f(_f32(p)), _f(out))
+    return out
+
+
+def rigid_inverse(pose):
+    out = np.zeros(7, np.float32)
+    lib().vo_rigid_inverse_f(_f(_f32(pose)), _f(out))
+    return out
+
+
+def compute_points3d(d0, xy0, d1, xy1, K4f, bf, pose):
+    d0, d1 = _f32(d0).reshape(-1, 256), _f32(d1).reshape(-1, 256)
+    xy0, xy1 = _i32(xy0), _i32(xy1)
+    good = np.zeros(len(d0), np.uint8); Pw = np.zeros((len(d0), 3), np.float32)
+    loc = np.zeros(len(d0), np.int32)
+    lib().vo_compute_points3d(_f(d0), _i(xy0), len(d0), _f(d1), _i(xy1), len(d1), _f(_f32(K4f)),
+                              C.c_float(bf), _f(_f32(pose)), good.ctypes.data_as(c_bp), _f(Pw), _i(loc))
+    return good, Pw, loc

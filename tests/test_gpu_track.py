@@ -1,0 +1,106 @@
+"""GPU parity tests of the tracking helpers (reprojection, searchProjection, removeOutlier,
+computePoint3d): integer pixels, chosen keypoints, claims and float world points bit-exact
+against the CPU oracle."""
+import numpy as np
+import pytest
+
+from visual_slam_amd import synth
+from visual_slam_amd import tracking as vt
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_reprojection_bit_exact(orc, seed):
+    pose, K4, Pw, _, _, _ = synth.make_tracking_frame(777, 10, seed=seed)
+    assert np.array_equal(vt.reproject_points(pose, K4, Pw), orc.reproject_points(pose, K4, Pw))
+
+
+def test_reprojection_degenerate_points(orc):
+    pose, K4, Pw, _, _, _ = synth.make_tracking_frame(64, 10, seed=3)
+    inv = orc.rigid_inverse(pose)
+    Pw[0] = orc.rigid_apply(inv, np.array([1.0, 0.0, 1.0], np.float32))      # depth 0 -> inf / nan
+    Pw[1] = orc.rigid_apply(inv, np.array([1.0, 1e-30, 1.0], np.float32))    # overflow
+    Pw[2] = orc.rigid_apply(inv, np.array([1.0, -2.0, 1.0], np.float32))     # behind the camera
+    assert np.array_equal(vt.reproject_points(pose, K4, Pw), orc.reproject_points(pose, K4, Pw))
+
+
+@pytest.mark.parametrize("n_tp,n_keys,seed,rivals", [(1, 1, 0, 0.0), (50, 3, 1, 0.2), (500, 600, 2, 0.15),
+                                                     (1500, 1000, 3, 0.4), (300, 2500, 4, 0.3)])
+def test_search_projection_matches_oracle(orc, n_tp, n_keys, seed, rivals):
+    pose, K4, Pw, desc, key_xy, key_desc = synth.make_tracking_frame(n_tp, n_keys, seed=seed, rivals=rivals)
+    re = orc.reproject_points(pose, K4, Pw)
+    want_t, want_c = orc.search_projection(re, desc, key_xy, key_desc, 2 * K4[2], 2 * K4[3], 30.0, 0.8)
+    got_t, got_c = vt.search_projection(pose, K4, Pw, desc, key_xy, key_desc, 30.0, 0.8)
+    assert np.array_equal(got_t, want_t)
+    assert np.array_equal(got_c, want_c)
+
+
+def test_search_projection_preclaimed_and_thresholds(orc):
+    pose, K4, Pw, desc, key_xy, key_desc = synth.make_tracking_frame(400, 500, seed=5, rivals=0.3)
+    re = orc.reproject_points(pose, K4, Pw)
+    claimed = (np.arange(500) % 3 == 0).astype(np.uint8)
+    for radius, accept in ((30.0, 0.8), (5.0, 0.8), (30.0, 0.3), (1000.0, 2.5)):
+        want_t, want_c = orc.search_projection(re, desc, key_xy, key_desc, 2 * K4[2], 2 * K4[3], radius, accept, claimed)
+        got_t, got_c = vt.search_projection(pose, K4, Pw, desc, key_xy, key_desc, radius, accept, claimed)
+        assert np.array_equal(got_t, want_t), (radius, accept)
+        assert np.array_equal(got_c, want_c), (radius, accept)
+
+
+def test_search_projection_crowded_window_takes_slow_path(orc):
+    # every keypoint in one spot with near-identical descriptors: candidate lists overflow and
+    # long claim chains form
+    pose, K4, Pw, desc, key_xy, key_desc = synth.make_tracking_frame(90, 120, seed=6, rivals=0.0)
+    Pw[:] = Pw[0]
+    rng = np.random.default_rng(0)
+    base = desc[0].copy()
+    desc[:] = base + 0.02 / 16 * rng.standard_normal(desc.shape).astype(np.float32)
+    desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+    key_desc[:] = base + 0.02 / 16 * rng.standard_normal(key_desc.shape).astype(np.float32)
+    key_desc /= np.linalg.norm(key_desc, axis=1, keepdims=True)
+    re = orc.reproject_points(pose, K4, Pw)
+    key_xy[:] = re[0] + rng.integers(-3, 4, key_xy.shape)
+    want_t, want_c = orc.search_projection(re, desc, key_xy, key_desc, 2 * K4[2], 2 * K4[3], 30.0, 0.8)
+    got_t, got_c = vt.search_projection(pose, K4, Pw, desc, key_xy, key_desc, 30.0, 0.8)
+    assert (want_t >= 0).sum() == 90
+    assert np.array_equal(got_t, want_t) and np.array_equal(got_c, want_c)
+
+
+def test_remove_outliers_matches_oracle(orc):
+    pose, K4, Pw, _, _, _ = synth.make_tracking_frame(1000, 10, seed=7)
+    re = orc.reproject_points(pose, K4, Pw)
+    rng = np.random.default_rng(1)
+    key_xy = re + rng.integers(-25, 26, re.shape).astype(np.int32)
+    key_xy[:50] = re[:50] + np.array([12, 16], np.int32)     # exactly 20 px: kept
+    tracks = rng.permutation(1000).astype(np.int32)
+    key_xy = key_xy[np.argsort(np.argsort(tracks))] if False else key_xy
+    tracks = np.arange(1000, dtype=np.int32)
+    tracks[rng.integers(0, 1000, 100)] = -1
+    want, n_want = orc.remove_outliers(pose, K4, Pw, key_xy, tracks)
+    got, n_got = vt.remove_outliers(pose, K4, Pw, key_xy, tracks)
+    assert np.array_equal(got, want) and n_got == n_want and n_want > 100
+
+
+@pytest.mark.parametrize("n0,n1,seed", [(1, 1, 0), (400, 420, 1), (1000, 64, 2), (2000, 2200, 3)])
+def test_compute_points3d_matches_oracle(orc, n0, n1, seed):
+    d0, xy0, d1, xy1, K4, bf, pose = synth.make_stereo_frame(n0, n1, seed=seed)
+    want_g, want_p, want_l = orc.compute_points3d(d0, xy0, d1, xy1, K4, bf, pose)
+    got_g, got_p, got_l = vt.compute_points3d(d0, xy0, d1, xy1, K4, bf, pose)
+    assert np.array_equal(got_l, want_l)
+    assert np.array_equal(got_g, want_g)
+    assert np.array_equal(bits(got_p), bits(want_p))
+
+
+def test_empty_inputs():
+    pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    K4 = np.array([170.5, 170.5, 191.5, 103.4], np.float32)
+    t, c = vt.search_projection(pose, K4, np.zeros((0, 3)), np.zeros((0, 256)), np.zeros((0, 2)), np.zeros((0, 256)))
+    assert len(t) == 0 and len(c) == 0
+    t, c = vt.search_projection(pose, K4, np.ones((4, 3)), np.ones((4, 256)), np.zeros((0, 2)), np.zeros((0, 256)))
+    assert np.array_equal(t, -np.ones(4, np.int32))
+    g, p, l = vt.compute_points3d(np.ones((3, 256)), np.zeros((3, 2)), np.zeros((0, 256)), np.zeros((0, 2)), K4, 20.0, pose)
+    assert not g.any() and np.array_equal(l, -np.ones(3, np.int32))

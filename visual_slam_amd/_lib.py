@@ -24,6 +24,7 @@ SYMBOLS = [
     "vs_matcher_create", "vs_matcher_destroy", "vs_matcher_set_stream", "vs_matcher_set_pair",
     "vs_matcher_run", "vs_matcher_get_matches", "vs_matcher_get_nn", "vs_matcher_get_rescans",
     "vs_match_two_way", "vs_match_stereo",
+    "vs_reproject_points", "vs_search_projection", "vs_remove_outliers", "vs_compute_points3d",
 ]
 
 

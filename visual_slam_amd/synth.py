@@ -161,3 +161,85 @@ def make_descriptors(n0=4096, n1=4096, seed=0, sigma=0.3, unmatched=0.3, duplica
 def make_keypoints(n, seed=0, width=383, height=207):
     rng = np.random.default_rng(0x4B50 + seed)
     return np.stack([rng.integers(0, width, n), rng.integers(0, height, n)], axis=1).astype(np.int32)
+
+
+def _quat_from_rpy(rpy):
+    """Unit quaternion (w, x, y, z) of Rz(yaw) * Ry(pitch) * Rx(roll)."""
+    r, p, y = [0.5 * float(a) for a in rpy]
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([cy * cp * cr + sy * sp * sr, cy * cp * sr - sy * sp * cr,
+                     cy * sp * cr + sy * cp * sr, sy * cp * cr - cy * sp * sr])
+
+
+def _quat_R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def make_tracking_frame(n_tp=500, n_keys=600, seed=0, rivals=0.15, pixel_noise=2.0, desc_sigma=0.25):
+    """One frame as Tracking::searchProjection sees it (src/core/tracking.cc:453-496): a float
+    pose Tcw (7 floats: t, quaternion wxyz), float intrinsics, tracked world points with
+    descriptors, and integer keypoints with descriptors.  Most keypoints are noisy reprojections
+    of tracked points; `rivals` of the tracked points are near-copies of another tracked point
+    (same place, similar descriptor), so that several points compete for one keypoint."""
+    rng = np.random.default_rng(0x7AC + seed)
+    K4 = np.array([170.5, 170.5, 191.5, 103.4], np.float32)
+    q = _quat_from_rpy(rng.normal(0, 0.05, 3))
+    t = rng.normal(0, 0.5, 3)
+    R = _quat_R(q)
+    depth = rng.uniform(1.0, 20.0, n_tp)
+    u = rng.uniform(-20, 2 * K4[2] + 20, n_tp)          # a few land outside the image
+    v = rng.uniform(-10, 2 * K4[3] + 10, n_tp)
+    Pc = np.stack([(u - K4[2]) / K4[0] * depth, depth, -(v - K4[3]) / K4[1] * depth], axis=1)
+    Pw = (Pc - t) @ R                                  # R^T (Pc - t)
+    desc = rng.standard_normal((n_tp, DESC_DIM))
+    desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+    n_riv = int(rivals * n_tp)
+    for k in range(n_riv):
+        a, b = rng.integers(0, n_tp, 2)
+        Pw[b] = Pw[a] + rng.normal(0, 0.002, 3)
+        desc[b] = desc[a] + 0.05 / np.sqrt(DESC_DIM) * rng.standard_normal(DESC_DIM)
+        desc[b] /= np.linalg.norm(desc[b])
+        u[b], v[b] = u[a], v[a]
+    n_match = min(n_keys, int(0.8 * n_tp))
+    src = rng.permutation(n_tp)[:n_match]
+    key_xy = np.empty((n_keys, 2), np.int32)
+    key_desc = rng.standard_normal((n_keys, DESC_DIM))
+    key_xy[:n_match, 0] = np.round(u[src] + rng.normal(0, pixel_noise, n_match))
+    key_xy[:n_match, 1] = np.round(v[src] + rng.normal(0, pixel_noise, n_match))
+    key_desc[:n_match] = desc[src] + desc_sigma / np.sqrt(DESC_DIM) * rng.standard_normal((n_match, DESC_DIM))
+    key_xy[n_match:, 0] = rng.integers(0, int(2 * K4[2]), n_keys - n_match)
+    key_xy[n_match:, 1] = rng.integers(0, int(2 * K4[3]), n_keys - n_match)
+    key_desc /= np.linalg.norm(key_desc, axis=1, keepdims=True)
+    perm = rng.permutation(n_keys)
+    pose = np.concatenate([t, q]).astype(np.float32)
+    return (pose, K4, np.ascontiguousarray(Pw.astype(np.float32)), np.ascontiguousarray(desc.astype(np.float32)),
+            np.ascontiguousarray(key_xy[perm]), np.ascontiguousarray(key_desc[perm].astype(np.float32)))
+
+
+def make_stereo_frame(n_left=400, n_right=420, seed=0, baseline_fx=0.12 * 170.5):
+    """Left/right keypoints and descriptors as Frame::computePoint3d sees them
+    (src/core/frame.cc:45-86): right keypoints are the left ones shifted by a disparity (some
+    <= 1, some negative), rows within a few pixels, descriptors noisy copies, plus distractors."""
+    rng = np.random.default_rng(0x57E + seed)
+    xy0 = make_keypoints(n_left, seed=seed + 100)
+    d0 = rng.standard_normal((n_left, DESC_DIM))
+    d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    n_m = min(n_right, int(0.8 * n_left))
+    src = rng.permutation(n_left)[:n_m]
+    disp = np.round(rng.uniform(-3, 60, n_m)).astype(np.int32)
+    xy1 = np.empty((n_right, 2), np.int32)
+    xy1[:n_m, 0] = xy0[src, 0] - disp
+    xy1[:n_m, 1] = xy0[src, 1] + rng.integers(-2, 3, n_m)
+    xy1[n_m:] = make_keypoints(n_right - n_m, seed=seed + 200)
+    d1 = rng.standard_normal((n_right, DESC_DIM))
+    d1[:n_m] = d0[src] + 0.3 / np.sqrt(DESC_DIM) * rng.standard_normal((n_m, DESC_DIM))
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    perm = rng.permutation(n_right)
+    q = _quat_from_rpy(rng.normal(0, 0.2, 3))
+    pose = np.concatenate([rng.normal(0, 1.0, 3), q]).astype(np.float32)
+    K4 = np.array([170.5, 170.5, 191.5, 103.4], np.float32)
+    return (np.ascontiguousarray(d0.astype(np.float32)), xy0, np.ascontiguousarray(d1[perm].astype(np.float32)),
+            np.ascontiguousarray(xy1[perm]), K4, np.float32(baseline_fx), pose)

@@ -179,6 +179,22 @@ def test_ragged_unobserved_points_and_cameras(orc):
     assert np.all(d1[5] == 0)
 
 
+def test_band_solver_matches_oracle_and_dense(orc, monkeypatch):
+    """Keyframes in time order give a block-banded reduced system: band-storage Cholesky."""
+    sc = synth.make_ba_scene(200, 3000, 4, band=8, seed=21)
+    ref, gpu = both(orc, sc)
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert rc == 0 and rel(d1, d0) < 1e-6 and rel(p1, p0) < 1e-6 and abs(m1 - m0) < 1e-8 * abs(m0)
+    monkeypatch.setenv("VS_BA_SOLVER", "dense")
+    d2, p2, m2 = gpu.lm_step(1e4)
+    assert rel(d2, d1) < 1e-8 and rel(p2, p1) < 1e-8
+    monkeypatch.delenv("VS_BA_SOLVER")
+    out0, out1 = ref.solve(), gpu.solve()
+    assert out1["iterations"] == out0["iterations"] and out1["termination"] == out0["termination"]
+    assert abs(out1["final_cost"] - out0["final_cost"]) < 1e-7 * out0["final_cost"]
+
+
 def test_sharded_partial_systems_sum_to_the_whole():
     sc = synth.make_ba_config("c1", seed=10)
     d = np.full(6 * sc.Nc, 0.3), np.full(3 * sc.Np, 0.3)

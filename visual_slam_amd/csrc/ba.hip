@@ -82,6 +82,7 @@ struct vs_ba {
     bool have_scale = false;
     int rank = 0, world = 1;
     HuberObs hub{ -1, -1, -1, 0.0 };
+    int max_pair_gap = 0;   // largest |a - b| over the camera pairs of the reduced system
     int nb_off = 0, n_diag_items = 0, n_off_items = 0, n_lm_blocks = 0, n_lm4_blocks = 0, item_waves = 4;
     bool stage_cams = false;
     int64_t red_len = 0;
@@ -211,9 +212,11 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     const int nb_off = (int)uniq.size();
     h->nb_off = nb_off;
     h->h_brow.resize((size_t)nb_off); h->h_bcol.resize((size_t)nb_off);
+    h->max_pair_gap = 0;
     for (int b = 0; b < nb_off; b++) {
         pmap.set(uniq[b], b);
         h->h_brow[b] = (int32_t)(uniq[b] >> 32); h->h_bcol[b] = (int32_t)(uniq[b] & 0xffffffffu);
+        h->max_pair_gap = std::max(h->max_pair_gap, h->h_bcol[b] - h->h_brow[b]);
     }
     // local entries per block (counting sort; landmarks ascending within a block)
     std::vector<int> bptr((size_t)nb_off + 1, 0);
@@ -437,16 +440,26 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         VS_TRY(launch_check("solve6_kernel"));
     } else {
         const int n = 6 * Nc;
-        VS_CHECK((int64_t)n * n * sizeof(real) <= (int64_t)8 << 30, VS_ERR_UNSUPPORTED,
-                 "dense reduced system of %d cameras exceeds this build's solver limit", Nc);
-        if (h->dense.n < (size_t)n * n) VS_TRY(h->dense.alloc((size_t)n * n));
-        VS_HIP(hipMemsetAsync(h->dense.p, 0, (size_t)n * n * sizeof(real), s));
+        // band storage when the camera pairs stay close to the diagonal (keyframes in time
+        // order), dense otherwise
+        const int band = 6 * h->max_pair_gap + 5;
+        bool banded = (int64_t)(band + 1) * 2 <= n;
+        if (const char *e = getenv("VS_BA_SOLVER")) banded = banded && strcmp(e, "dense") != 0;   // test knob
+        const int bw = banded ? band : n;
+        const int64_t ld = banded ? band : n;
+        const size_t elems = banded ? (size_t)n * (band + 1) : (size_t)n * n;
+        VS_CHECK(elems * sizeof(real) <= (size_t)16 << 30, VS_ERR_UNSUPPORTED,
+                 "reduced system of %d cameras with camera-pair gap %d exceeds this build's solver limit (16 GiB)",
+                 Nc, h->max_pair_gap);
+        if (h->dense.n < elems) VS_TRY(h->dense.alloc(elems));
+        VS_HIP(hipMemsetAsync(h->dense.p, 0, elems * sizeof(real), s));
+        real *A = h->dense.p + (banded ? band : 0);
         const int64_t ne = (int64_t)Nc * 36 + (int64_t)h->nb_off * 36;
         hipLaunchKernelGGL(assemble_lower_kernel, dim3(div_up(ne, 256)), dim3(256), 0, s, Nc, h->nb_off,
-                           h->brow.p, h->bcol.p, h->S_diag(), h->S_off(), h->dense.p, n);
+                           h->brow.p, h->bcol.p, h->S_diag(), h->S_off(), A, ld);
         VS_TRY(launch_check("assemble_lower_kernel"));
         VS_HIP(hipMemcpyAsync(h->dcam.p, h->rhs(), (size_t)n * sizeof(real), hipMemcpyDeviceToDevice, s));
-        VS_TRY(dense_cholesky_solve(h->dense.p, h->dcam.p, n, h->info.p, h->linv.p, s));
+        VS_TRY(cholesky_solve(A, h->dcam.p, n, ld, bw, h->info.p, h->linv.p, s));
     }
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)

@@ -1,5 +1,10 @@
-// Dense symmetric positive-definite solve of the reduced camera system on the device:
-// blocked right-looking Cholesky (lower, in place, row-major) + triangular solves.
+// Symmetric positive-definite solve of the reduced camera system on the device: blocked
+// right-looking Cholesky (lower, in place) + triangular solves, on dense or BAND storage.
+//
+// Storage: element (i, j), j <= i, i - j <= bw, lives at A[i * ld + j].  Dense: ld = n, bw = n.
+// Band (lower half-bandwidth bw): ld = bw and A points bw elements into an n * (bw + 1) array, so
+// that row i occupies the bw + 1 consecutive slots ending at its diagonal; Cholesky fill-in stays
+// inside the band, and every kernel below touches in-band elements only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ba_kernels.h"
@@ -9,36 +14,36 @@ namespace vs {
 constexpr int kNB = 32;    // Cholesky panel width
 constexpr int kTile = 64;  // trailing-update tile
 
-// Scatter the stored upper-triangular 6x6 blocks into the LOWER triangle of a dense n x n
-// row-major matrix (n = 6*Nc).  One thread per block element.
+// Scatter the stored upper-triangular 6x6 blocks into the LOWER triangle.  One thread per block
+// element.
 __global__ void assemble_lower_kernel(int Nc, int nb_off, const int *__restrict__ brow,
                                       const int *__restrict__ bcol,
                                       const real *__restrict__ S_diag,
-                                      const real *__restrict__ S_off, real *__restrict__ A, int n)
+                                      const real *__restrict__ S_off, real *__restrict__ A, int64_t ld)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nd = (int64_t)Nc * 36;
     if (tid < nd) {
         const int c = (int)(tid / 36), p = (int)(tid % 36) / 6, q = (int)(tid % 6);
-        if (q <= p) A[(int64_t)(6 * c + p) * n + 6 * c + q] = S_diag[tid];
+        if (q <= p) A[(int64_t)(6 * c + p) * ld + 6 * c + q] = S_diag[tid];
     } else if (tid < nd + (int64_t)nb_off * 36) {
         const int64_t u = tid - nd;
         const int blk = (int)(u / 36), p = (int)(u % 36) / 6, q = (int)(u % 6);
         const int a = brow[blk], b = bcol[blk];   // a < b: S_ab[p][q] = S_ba[q][p] (lower)
-        A[(int64_t)(6 * b + q) * n + 6 * a + p] = S_off[u];
+        A[(int64_t)(6 * b + q) * ld + 6 * a + p] = S_off[u];
     }
 }
 
 // Factor the nb x nb diagonal block at k0 (one workgroup of 32x32 threads) and write the
 // inverse of its Cholesky factor (identity-padded to 32 x 32, row-major) to Linv.
 __global__ void __launch_bounds__(kNB *kNB)
-potrf_diag_kernel(real *__restrict__ A, int n, int k0, int nb, int *__restrict__ info,
+potrf_diag_kernel(real *__restrict__ A, int64_t ld, int k0, int nb, int *__restrict__ info,
                   real *__restrict__ Linv)
 {
     __shared__ real L[kNB][kNB + 1];
     __shared__ real Li[kNB][kNB + 1];
     const int i = threadIdx.y, j = threadIdx.x;
-    L[i][j] = (i < nb && j <= i) ? A[(int64_t)(k0 + i) * n + k0 + j] : (i == j ? real(1) : real(0));
+    L[i][j] = (i < nb && j <= i) ? A[(int64_t)(k0 + i) * ld + k0 + j] : (i == j ? real(1) : real(0));
     Li[i][j] = real(0);
     __syncthreads();
     for (int c = 0; c < nb; c++) {
@@ -53,7 +58,7 @@ potrf_diag_kernel(real *__restrict__ A, int n, int k0, int nb, int *__restrict__
         if (i > c && j > c && j <= i && i < nb) L[i][j] -= L[i][c] * L[j][c];
         __syncthreads();
     }
-    if (i < nb && j <= i) A[(int64_t)(k0 + i) * n + k0 + j] = L[i][j];
+    if (i < nb && j <= i) A[(int64_t)(k0 + i) * ld + k0 + j] = L[i][j];
     // column j of L^-1 by forward substitution (thread row 0 only; 32 independent columns)
     if (i == 0) {
         Li[j][j] = real(1) / L[j][j];
@@ -70,24 +75,26 @@ potrf_diag_kernel(real *__restrict__ A, int n, int k0, int nb, int *__restrict__
 // Panel solve: rows i >= k0+nb:  X[i][:] = A[i][k0:k0+nb] * L_kk^-T = A_row * Linv^T.
 // 32 x 32 threads: thread (c, r) forms X[row r][c] = sum_{m <= c} A[r][m] * Linv[c][m].
 __global__ void __launch_bounds__(kNB *kNB)
-trsm_panel_kernel(real *__restrict__ A, int n, int k0, int nb, const real *__restrict__ Linv)
+trsm_panel_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int k0, int nb,
+                  const real *__restrict__ Linv)
 {
     __shared__ real Li[kNB][kNB + 1];
     __shared__ real Ar[kNB][kNB + 1];
     const int c = threadIdx.x, r = threadIdx.y;
     const int i = k0 + nb + blockIdx.x * kNB + r;
+    const bool in = i < n && c < nb && i - (k0 + c) <= bw;
     Li[r][c] = Linv[r * kNB + c];
-    Ar[r][c] = (i < n && c < nb) ? A[(int64_t)i * n + k0 + c] : real(0);
+    Ar[r][c] = in ? A[(int64_t)i * ld + k0 + c] : real(0);
     __syncthreads();
     real s = real(0);
     for (int m = 0; m <= c; m++) s += Ar[r][m] * Li[c][m];
-    if (i < n && c < nb) A[(int64_t)i * n + k0 + c] = s;
+    if (in) A[(int64_t)i * ld + k0 + c] = s;
 }
 
 // Trailing update of the lower triangle: A[i][j] -= sum_m X[i][m] X[j][m] for
 // i,j >= k0+nb, j <= i.  64x64 tiles, 16x16 threads, 4x4 outputs per thread.
 __global__ void __launch_bounds__(256)
-syrk_update_kernel(real *__restrict__ A, int n, int k0, int nb)
+syrk_update_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int k0, int nb)
 {
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;
@@ -97,8 +104,8 @@ syrk_update_kernel(real *__restrict__ A, int n, int k0, int nb)
     const int i0 = base + ti * kTile, j0 = base + tj * kTile;
     for (int e = threadIdx.x; e < kTile * kNB; e += 256) {
         const int r = e / kNB, c = e % kNB;
-        Xi[r][c] = (i0 + r < n && c < nb) ? A[(int64_t)(i0 + r) * n + k0 + c] : real(0);
-        Xj[r][c] = (j0 + r < n && c < nb) ? A[(int64_t)(j0 + r) * n + k0 + c] : real(0);
+        Xi[r][c] = (i0 + r < n && c < nb && i0 + r - (k0 + c) <= bw) ? A[(int64_t)(i0 + r) * ld + k0 + c] : real(0);
+        Xj[r][c] = (j0 + r < n && c < nb && j0 + r - (k0 + c) <= bw) ? A[(int64_t)(j0 + r) * ld + k0 + c] : real(0);
     }
     __syncthreads();
     const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
@@ -122,13 +129,13 @@ syrk_update_kernel(real *__restrict__ A, int n, int k0, int nb)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
-            if (i < n && j <= i) A[(int64_t)i * n + j] -= acc[a][b];
+            if (i < n && j <= i && i - j <= bw) A[(int64_t)i * ld + j] -= acc[a][b];
         }
 }
 
 // Solve L y = b then L^T x = y in place (single workgroup, 1024 threads), L = lower of A.
 __global__ void __launch_bounds__(1024)
-chol_trsv_kernel(const real *__restrict__ A, int n, real *__restrict__ b)
+chol_trsv_kernel(const real *__restrict__ A, int n, int64_t ld, int bw, real *__restrict__ b)
 {
     __shared__ real y[kNB];
     const int tid = threadIdx.x;
@@ -138,17 +145,19 @@ chol_trsv_kernel(const real *__restrict__ A, int n, real *__restrict__ b)
         if (tid == 0) {
             for (int c = 0; c < nb; c++) {
                 real s = b[k0 + c];
-                const real *row = A + (int64_t)(k0 + c) * n + k0;
+                const real *row = A + (int64_t)(k0 + c) * ld + k0;
                 for (int m = 0; m < c; m++) s -= row[m] * y[m];
                 y[c] = s / row[c];
             }
             for (int c = 0; c < nb; c++) b[k0 + c] = y[c];
         }
         __syncthreads();
-        for (int i = k0 + nb + tid; i < n; i += 1024) {
-            const real *row = A + (int64_t)i * n + k0;
+        const int i_end = min(n, k0 + nb + bw);
+        for (int i = k0 + nb + tid; i < i_end; i += 1024) {
+            const real *row = A + (int64_t)i * ld + k0;
             real s = real(0);
-            for (int m = 0; m < nb; m++) s += row[m] * y[m];
+            for (int m = 0; m < nb; m++)
+                if (i - (k0 + m) <= bw) s += row[m] * y[m];
             b[i] -= s;
         }
         __syncthreads();
@@ -159,15 +168,16 @@ chol_trsv_kernel(const real *__restrict__ A, int n, real *__restrict__ b)
         if (tid == 0) {
             for (int c = nb - 1; c >= 0; c--) {
                 real s = b[k0 + c];
-                for (int m = c + 1; m < nb; m++) s -= A[(int64_t)(k0 + m) * n + k0 + c] * y[m];
-                y[c] = s / A[(int64_t)(k0 + c) * n + k0 + c];
+                for (int m = c + 1; m < nb; m++) s -= A[(int64_t)(k0 + m) * ld + k0 + c] * y[m];
+                y[c] = s / A[(int64_t)(k0 + c) * ld + k0 + c];
             }
             for (int c = 0; c < nb; c++) b[k0 + c] = y[c];
         }
         __syncthreads();
-        for (int i = tid; i < k0; i += 1024) {
+        for (int i = max(0, k0 - bw) + tid; i < k0; i += 1024) {
             real s = real(0);
-            for (int m = 0; m < nb; m++) s += A[(int64_t)(k0 + m) * n + i] * y[m];
+            for (int m = 0; m < nb; m++)
+                if (k0 + m - i <= bw) s += A[(int64_t)(k0 + m) * ld + i] * y[m];
             b[i] -= s;
         }
         __syncthreads();
@@ -223,25 +233,27 @@ __global__ void solve6_kernel(int Nc, const real *__restrict__ S_diag, const rea
     if (bad && *info == 0) *info = c + 1;
 }
 
-// Factor + solve.  A: n x n dense row-major with the lower triangle filled; b: rhs, overwritten
-// with the solution; info (device int, zeroed by the caller): first failing pivot + 1, or 0;
-// Linv: device workspace of 32 x 32 reals.
-static inline int dense_cholesky_solve(real *A, real *b, int n, int *info, real *Linv, hipStream_t s)
+// Factor + solve.  A, ld, bw: storage as described at the top of this file, lower triangle
+// filled; b: rhs, overwritten with the solution; info (device int, zeroed by the caller): first
+// failing pivot + 1, or 0; Linv: device workspace of 32 x 32 reals.
+static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, int *info, real *Linv,
+                                 hipStream_t s)
 {
     for (int k0 = 0; k0 < n; k0 += kNB) {
         const int nb = n - k0 < kNB ? n - k0 : kNB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(kNB, kNB), 0, s, A, n, k0, nb, info, Linv);
-        const int rem = n - k0 - nb;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(kNB, kNB), 0, s, A, ld, k0, nb, info, Linv);
+        int rem = n - k0 - nb;
+        if (rem > bw) rem = bw;   // rows further down hold no in-band element of this panel
         if (rem > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + kNB - 1) / kNB), dim3(kNB, kNB), 0, s, A, n, k0, nb, Linv);
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + kNB - 1) / kNB), dim3(kNB, kNB), 0, s, A, n, ld, bw, k0, nb, Linv);
             const int nt = (rem + kTile - 1) / kTile;
-            hipLaunchKernelGGL(syrk_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, n, k0, nb);
+            hipLaunchKernelGGL(syrk_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, n, ld, bw, k0, nb);
         }
     }
-    hipLaunchKernelGGL(chol_trsv_kernel, dim3(1), dim3(1024), 0, s, A, n, b);
+    hipLaunchKernelGGL(chol_trsv_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        set_error("dense Cholesky launch failed: %s", hipGetErrorString(e));
+        set_error("Cholesky launch failed: %s", hipGetErrorString(e));
         return VS_ERR_HIP;
     }
     return VS_OK;

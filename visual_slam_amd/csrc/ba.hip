@@ -459,6 +459,8 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
                            h->brow.p, h->bcol.p, h->S_diag(), h->S_off(), A, ld);
         VS_TRY(launch_check("assemble_lower_kernel"));
         VS_HIP(hipMemcpyAsync(h->dcam.p, h->rhs(), (size_t)n * sizeof(real), hipMemcpyDeviceToDevice, s));
+        const size_t linv_elems = (size_t)div_up(n, kNB) * kNB * kNB;
+        if (h->linv.n < linv_elems) VS_TRY(h->linv.alloc(linv_elems));
         VS_TRY(cholesky_solve(A, h->dcam.p, n, ld, bw, h->info.p, h->linv.p, s));
     }
     const size_t lds = cam_lds_bytes(h);

@@ -34,42 +34,84 @@ __global__ void assemble_lower_kernel(int Nc, int nb_off, const int *__restrict_
     }
 }
 
-// Factor the nb x nb diagonal block at k0 (one workgroup of 32x32 threads) and write the
-// inverse of its Cholesky factor (identity-padded to 32 x 32, row-major) to Linv.
+// Cholesky of the 32 x 32 block held in LDS by a whole workgroup of 32 x 32 threads (thread
+// (i, j) = element (i, j)); W is the working copy (identity-padded beyond nb), F receives the
+// factor.  Column c of W is final after step c - 1 and is never rewritten, so a step reads it,
+// updates the columns to its right and emits column c of F with ONE barrier.
+// Returns the first failing pivot + 1 (pivot replaced by 1) or 0; uniform over the workgroup.
+// 1 / sqrt(d) to double precision: hardware estimate + two Newton steps (d > 0, normal range).
+__device__ __forceinline__ real rsqrt_refined(real d)
+{
+    real y = __builtin_amdgcn_rsq(d);
+    const real hd = real(0.5) * d;
+    y = y * fma(-hd * y, y, real(1.5));
+    y = y * fma(-hd * y, y, real(1.5));
+    return y;
+}
+
+__device__ __forceinline__ int potrf32_block(real (*W)[kNB + 1], real (*F)[kNB + 1], int nb, int i, int j)
+{
+    int bad = 0;
+    for (int c = 0; c < nb; c++) {
+        real d = W[c][c];
+        if (!(d > real(0))) { if (bad == 0) bad = c + 1; d = real(1); }
+        const real rs = rsqrt_refined(d);
+        const real la = W[i][c] * rs, lb = W[j][c] * rs;     // column c of the factor at rows i, j
+        if (j > c && j <= i && i < nb) W[i][j] = fma(-la, lb, W[i][j]);
+        if (j == c && i >= c) F[i][c] = i == c ? d * rs : (i < nb ? la : real(0));
+        __syncthreads();
+    }
+    return bad;
+}
+
+// Inverse of the lower-triangular 32 x 32 factor F (identity-padded) by a workgroup of 32 x 32
+// threads: forward substitution on the identity held in X, one barrier per row.  Row c of the
+// inverse is X[c][:] / F[c][c] once rows < c are eliminated; it goes straight to `out` (row-major
+// 32 x 32) and X keeps the unnormalised row, which no later step reads.
+__device__ __forceinline__ void trinv32_block(real (*F)[kNB + 1], real (*X)[kNB + 1], int nb, int i, int j,
+                                              real *__restrict__ out)
+{
+    X[i][j] = i == j ? real(1) : real(0);
+    __syncthreads();
+    for (int c = 0; c < kNB; c++) {
+        const real dc = c < nb ? F[c][c] : real(1);
+        const real xc = X[c][j] / dc;
+        if (i == c) out[c * kNB + j] = xc;
+        else if (i > c && i < nb) X[i][j] = fma(-F[i][c], xc, X[i][j]);
+        __syncthreads();
+    }
+}
+
+// Factor the nb x nb diagonal block at k0 and write the inverse of its Cholesky factor
+// (identity-padded to 32 x 32, row-major) to Linv.  One workgroup of 32 x 32 threads.
 __global__ void __launch_bounds__(kNB *kNB)
 potrf_diag_kernel(real *__restrict__ A, int64_t ld, int k0, int nb, int *__restrict__ info,
                   real *__restrict__ Linv)
 {
-    __shared__ real L[kNB][kNB + 1];
-    __shared__ real Li[kNB][kNB + 1];
-    const int i = threadIdx.y, j = threadIdx.x;
-    L[i][j] = (i < nb && j <= i) ? A[(int64_t)(k0 + i) * ld + k0 + j] : (i == j ? real(1) : real(0));
-    Li[i][j] = real(0);
+    __shared__ real W[kNB][kNB + 1];
+    __shared__ real F[kNB][kNB + 1];
+    const int i = threadIdx.x / kNB, j = threadIdx.x % kNB;
+    W[i][j] = (i < nb && j <= i) ? A[(int64_t)(k0 + i) * ld + k0 + j] : (i == j ? real(1) : real(0));
+    F[i][j] = real(0);
     __syncthreads();
-    for (int c = 0; c < nb; c++) {
-        if (i == c && j == c) {
-            const real d = L[c][c];
-            if (!(d > real(0))) { if (*info == 0) *info = k0 + c + 1; L[c][c] = real(1); }
-            else L[c][c] = sqrt(d);
-        }
-        __syncthreads();
-        if (j == c && i > c && i < nb) L[i][c] /= L[c][c];
-        __syncthreads();
-        if (i > c && j > c && j <= i && i < nb) L[i][j] -= L[i][c] * L[j][c];
-        __syncthreads();
-    }
-    if (i < nb && j <= i) A[(int64_t)(k0 + i) * ld + k0 + j] = L[i][j];
-    // column j of L^-1 by forward substitution (thread row 0 only; 32 independent columns)
-    if (i == 0) {
-        Li[j][j] = real(1) / L[j][j];
-        for (int r = j + 1; r < kNB; r++) {
-            real s = real(0);
-            for (int m = j; m < r; m++) s += L[r][m] * Li[m][j];
-            Li[r][j] = -s / L[r][r];
-        }
-    }
+    const int bad = potrf32_block(W, F, nb, i, j);
+    if (bad && threadIdx.x == 0 && *info == 0) *info = k0 + bad;
+    if (i < nb && j <= i) A[(int64_t)(k0 + i) * ld + k0 + j] = F[i][j];
     __syncthreads();
-    Linv[i * kNB + j] = Li[i][j];
+    trinv32_block(F, W, nb, i, j, Linv);
+}
+
+// Inverses of all diagonal blocks of a finished factor, one workgroup per 32-column panel.
+__global__ void __launch_bounds__(kNB *kNB)
+trinv_panels_kernel(const real *__restrict__ A, int n, int64_t ld, real *__restrict__ Linv)
+{
+    __shared__ real F[kNB][kNB + 1];
+    __shared__ real X[kNB][kNB + 1];
+    const int k0 = blockIdx.x * kNB, nb = min(kNB, n - k0);
+    const int i = threadIdx.x / kNB, j = threadIdx.x % kNB;
+    F[i][j] = (i < nb && j <= i) ? A[(int64_t)(k0 + i) * ld + k0 + j] : (i == j ? real(1) : real(0));
+    __syncthreads();
+    trinv32_block(F, X, nb, i, j, Linv + (int64_t)blockIdx.x * kNB * kNB);
 }
 
 // Panel solve: rows i >= k0+nb:  X[i][:] = A[i][k0:k0+nb] * L_kk^-T = A_row * Linv^T.
@@ -133,31 +175,133 @@ syrk_update_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int k0, int 
         }
 }
 
-// Solve L y = b then L^T x = y in place (single workgroup, 1024 threads), L = lower of A.
+// Whole factorisation in ONE workgroup (1024 threads) for systems whose trailing window is
+// narrow (band) or small (few cameras): per 32-column panel, the workgroup factors the diagonal
+// block, one thread per row forms the panel X = A_panel * L_kk^-T by forward substitution into
+// LDS, and all threads apply the trailing update to the bw x bw window.  No launches between
+// panels; the window lives in L2.  The block inverses the triangular solves use are formed
+// afterwards for all panels at once (trinv_panels_kernel).
+constexpr int kFusedMaxRows = 448;   // panel rows held in LDS (>= min(bw, n))
+
 __global__ void __launch_bounds__(1024)
-chol_trsv_kernel(const real *__restrict__ A, int n, int64_t ld, int bw, real *__restrict__ b)
+chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restrict__ info)
+{
+    __shared__ real W[kNB][kNB + 1];
+    __shared__ real F[kNB][kNB + 1];
+    __shared__ real invd[kNB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    real (*X)[kNB + 1] = reinterpret_cast<real (*)[kNB + 1]>(dyn_lds);
+    const int tid = threadIdx.x;
+    const int bi = tid / kNB, bj = tid % kNB;
+    for (int k0 = 0; k0 < n; k0 += kNB) {
+        const int nb = min(kNB, n - k0);
+        W[bi][bj] = (bi < nb && bj <= bi) ? A[(int64_t)(k0 + bi) * ld + k0 + bj] : (bi == bj ? real(1) : real(0));
+        F[bi][bj] = real(0);
+        __syncthreads();
+        const int bad = potrf32_block(W, F, nb, bi, bj);
+        if (bad && tid == 0 && *info == 0) *info = k0 + bad;
+        if (bi < nb && bj <= bi) A[(int64_t)(k0 + bi) * ld + k0 + bj] = F[bi][bj];
+        if (tid < kNB) invd[tid] = tid < nb ? real(1) / F[tid][tid] : real(1);
+        __syncthreads();
+        const int base = k0 + nb;
+        const int rem = min(n - base, bw);
+        if (rem <= 0) break;                         // uniform: last panel
+        // panel row r: x[c] = (a[c] - sum_{m < c} x[m] F[c][m]) / F[c][c]; out-of-band a[m] = 0
+        if (tid < rem) {
+            const int i = base + tid;
+            const real *row = A + (int64_t)i * ld + k0;
+            const int m_lo = max(0, i - k0 - bw);
+            real *xr = X[tid];                       // the thread's own LDS row
+            for (int c = 0; c < kNB; c++) {
+                const bool in = c >= m_lo && c < nb;
+                xr[c] = in ? row[c] : real(0);
+            }
+            for (int c = 0; c < nb; c++) {
+                real sum = xr[c];
+                const real *fc = F[c];
+#pragma unroll 8
+                for (int m = 0; m < c; m++) sum = fma(-xr[m], fc[m], sum);
+                sum *= invd[c];
+                xr[c] = sum;
+                if (c >= m_lo) A[(int64_t)i * ld + k0 + c] = sum;
+            }
+        }
+        __syncthreads();
+        // trailing update, 4 x 4 outputs per thread over 64 x 64 tiles of the lower triangle
+        const int nt = (rem + kTile - 1) / kTile;
+        const int n_tiles = nt * (nt + 1) / 2;
+        const int sub = tid & 255, ty = sub / 16, tx = sub % 16;
+        for (int t = tid >> 8; t < n_tiles; t += 4) {
+            int ti = 0, acc_t = 0;
+            while (acc_t + ti + 1 <= t) { acc_t += ti + 1; ti++; }
+            const int tj = t - acc_t;
+            real acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = real(0);
+            int ri[4], rj[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                ri[a] = min(ti * kTile + ty + 16 * a, rem - 1);
+                rj[a] = min(tj * kTile + tx + 16 * a, rem - 1);
+            }
+#pragma unroll 4
+            for (int m = 0; m < kNB; m++) {
+                real xi[4], xj[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) { xi[a] = X[ri[a]][m]; xj[a] = X[rj[a]][m]; }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) acc[a][b] = fma(xi[a], xj[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int r = ti * kTile + ty + 16 * a, c = tj * kTile + tx + 16 * b;
+                    if (r < rem && c <= r) A[(int64_t)(base + r) * ld + base + c] -= acc[a][b];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// Solve L y = b then L^T x = y in place (single workgroup, 1024 threads), L = lower of A.
+// Linv holds the inverse of every 32 x 32 diagonal block of L (panel p at Linv + 1024 p), so a
+// block solve is a 32 x 32 matrix-vector product.
+__global__ void __launch_bounds__(1024)
+chol_trsv_kernel(const real *__restrict__ A, int n, int64_t ld, int bw, const real *__restrict__ Linv,
+                 real *__restrict__ b)
 {
     __shared__ real y[kNB];
+    __shared__ real bp[kNB];
     const int tid = threadIdx.x;
     // forward
     for (int k0 = 0; k0 < n; k0 += kNB) {
         const int nb = min(kNB, n - k0);
-        if (tid == 0) {
-            for (int c = 0; c < nb; c++) {
-                real s = b[k0 + c];
-                const real *row = A + (int64_t)(k0 + c) * ld + k0;
-                for (int m = 0; m < c; m++) s -= row[m] * y[m];
-                y[c] = s / row[c];
-            }
-            for (int c = 0; c < nb; c++) b[k0 + c] = y[c];
+        const real *Li = Linv + (int64_t)(k0 / kNB) * kNB * kNB;
+        if (tid < kNB) bp[tid] = tid < nb ? b[k0 + tid] : real(0);
+        __syncthreads();
+        if (tid < kNB) {
+            real s = real(0);
+#pragma unroll
+            for (int m = 0; m < kNB; m++) s = fma(Li[tid * kNB + m], bp[m], s);   // zero above the diagonal
+            y[tid] = s;
+            if (tid < nb) b[k0 + tid] = s;
         }
         __syncthreads();
         const int i_end = min(n, k0 + nb + bw);
         for (int i = k0 + nb + tid; i < i_end; i += 1024) {
             const real *row = A + (int64_t)i * ld + k0;
+            const int m_lo = max(0, i - k0 - bw);                                     // in-band part
             real s = real(0);
-            for (int m = 0; m < nb; m++)
-                if (i - (k0 + m) <= bw) s += row[m] * y[m];
+#pragma unroll
+            for (int m = 0; m < kNB; m++) {
+                const real v = row[max(m, m_lo)];
+                s = fma(m >= m_lo ? v : real(0), y[m], s);                             // y[m] = 0 for m >= nb
+            }
             b[i] -= s;
         }
         __syncthreads();
@@ -165,19 +309,25 @@ chol_trsv_kernel(const real *__restrict__ A, int n, int64_t ld, int bw, real *__
     // backward
     for (int k0 = ((n - 1) / kNB) * kNB; k0 >= 0; k0 -= kNB) {
         const int nb = min(kNB, n - k0);
-        if (tid == 0) {
-            for (int c = nb - 1; c >= 0; c--) {
-                real s = b[k0 + c];
-                for (int m = c + 1; m < nb; m++) s -= A[(int64_t)(k0 + m) * ld + k0 + c] * y[m];
-                y[c] = s / A[(int64_t)(k0 + c) * ld + k0 + c];
-            }
-            for (int c = 0; c < nb; c++) b[k0 + c] = y[c];
+        const real *Li = Linv + (int64_t)(k0 / kNB) * kNB * kNB;
+        if (tid < kNB) bp[tid] = tid < nb ? b[k0 + tid] : real(0);
+        __syncthreads();
+        if (tid < kNB) {
+            real s = real(0);
+#pragma unroll
+            for (int m = 0; m < kNB; m++) s = fma(Li[m * kNB + tid], bp[m], s);   // (L^-1)^T
+            y[tid] = s;
+            if (tid < nb) b[k0 + tid] = s;
         }
         __syncthreads();
         for (int i = max(0, k0 - bw) + tid; i < k0; i += 1024) {
             real s = real(0);
-            for (int m = 0; m < nb; m++)
-                if (k0 + m - i <= bw) s += A[(int64_t)(k0 + m) * ld + i] * y[m];
+            const int m_end = min(nb, bw + i - k0 + 1);                                // in-band part
+#pragma unroll
+            for (int m = 0; m < kNB; m++) {
+                const real v = A[(int64_t)(k0 + min(m, m_end - 1)) * ld + i];
+                s = fma(m < m_end ? v : real(0), y[m], s);
+            }
             b[i] -= s;
         }
         __syncthreads();
@@ -235,22 +385,39 @@ __global__ void solve6_kernel(int Nc, const real *__restrict__ S_diag, const rea
 
 // Factor + solve.  A, ld, bw: storage as described at the top of this file, lower triangle
 // filled; b: rhs, overwritten with the solution; info (device int, zeroed by the caller): first
-// failing pivot + 1, or 0; Linv: device workspace of 32 x 32 reals.
+// failing pivot + 1, or 0; Linv: device workspace of ceil(n / 32) * 32 * 32 reals.
 static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, int *info, real *Linv,
                                  hipStream_t s)
 {
+    const int window = bw < n ? bw : n;
+    if (window <= kFusedMaxRows) {
+        const size_t lds = (size_t)window * (kNB + 1) * sizeof(real);
+        static bool lds_limit_raised = false;     // dynamic LDS beyond the default limit
+        if (!lds_limit_raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kFusedMaxRows * (kNB + 1) * (int)sizeof(real)) != hipSuccess) {
+                set_error("cannot raise the dynamic LDS limit of the fused Cholesky kernel");
+                return VS_ERR_HIP;
+            }
+            lds_limit_raised = true;
+        }
+        hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(1024), lds, s, A, n, ld, bw, info);
+        hipLaunchKernelGGL(trinv_panels_kernel, dim3((n + kNB - 1) / kNB), dim3(kNB * kNB), 0, s, A, n, ld, Linv);
+    } else
     for (int k0 = 0; k0 < n; k0 += kNB) {
         const int nb = n - k0 < kNB ? n - k0 : kNB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(kNB, kNB), 0, s, A, ld, k0, nb, info, Linv);
+        real *Lp = Linv + (int64_t)(k0 / kNB) * kNB * kNB;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(kNB * kNB), 0, s, A, ld, k0, nb, info, Lp);
         int rem = n - k0 - nb;
         if (rem > bw) rem = bw;   // rows further down hold no in-band element of this panel
         if (rem > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + kNB - 1) / kNB), dim3(kNB, kNB), 0, s, A, n, ld, bw, k0, nb, Linv);
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + kNB - 1) / kNB), dim3(kNB, kNB), 0, s, A, n, ld, bw, k0, nb, Lp);
             const int nt = (rem + kTile - 1) / kTile;
             hipLaunchKernelGGL(syrk_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, n, ld, bw, k0, nb);
         }
     }
-    hipLaunchKernelGGL(chol_trsv_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, b);
+    hipLaunchKernelGGL(chol_trsv_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("Cholesky launch failed: %s", hipGetErrorString(e));

@@ -105,14 +105,33 @@ def bench_ba(args, rank, world, dist, torch):
         kern_sum = float(sum(k_ms.values()))
         dom = max(k_ms, key=k_ms.get)
         achieved = alg / (kern_sum * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic(args.workload) if world == 1 else (None, None)
         out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                               frac=achieved / HBM_PEAK_GBS, traffic=None,
+                               frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                                kernel="fused linearise pipeline: prep_cameras + landmark + blocks + finalize kernels "
                                       "(HIP-event intervals, each carrying ~5 us of event overhead)",
                                dominant_kernel=dom, kernels_ms=k_ms, pipeline_ms=float(ms[5]),
                                algorithmic_bytes=int(alg))
     ba.close()
     return out
+
+
+def committed_traffic(workload):
+    """HBM bytes per linearise pass from the committed rocprofv3 PMC passes under profiles/
+    (FETCH_SIZE and WRITE_SIZE are kilobytes; FETCH_SIZE is doubled as the gfx950 counter tallies
+    128-byte requests of 16-byte-per-lane reads at 64 bytes).  None when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_summary.json")))
+    if not files:
+        return None, None
+    pmc = json.load(open(files[-1])).get("pmc_avg_per_dispatch", {})
+    f, w = pmc.get(workload + "_fetch"), pmc.get(workload + "_write")
+    if not f or not w:
+        return None, None
+    keys = ("prep_cameras_kernel", "landmark_kernel", "blocks_kernel", "finalize_kernel")
+    fetch = sum(v["FETCH_SIZE"] for k, v in f.items() if any(x in k for x in keys))
+    write = sum(v["WRITE_SIZE"] for k, v in w.items() if any(x in k for x in keys))
+    return int((2.0 * fetch + write) * 1024), os.path.basename(files[-1])
 
 
 def kernel_times(ms):

@@ -20,13 +20,17 @@ run_trace c2 python3 bench.py --steps 100 --warmup 10 --no-extra --no-cpu &&
 run_trace c4 python3 tools/prof_ba.py c4 20 &&
 run_trace c5shard python3 tools/prof_ba.py c5shard 20 &&
 run_trace match python3 tools/prof_match.py 64 3 &&
+run_trace lm_c2 python3 tools/time_lm.py c2 &&
+run_trace lm_c5shard python3 tools/time_lm.py c5shard &&
 run_pmc c2_fetch FETCH_SIZE python3 tools/prof_ba.py c2 5 &&
 run_pmc c2_write WRITE_SIZE python3 tools/prof_ba.py c2 5 &&
 run_pmc c4_fetch FETCH_SIZE python3 tools/prof_ba.py c4 5 &&
 run_pmc c4_write WRITE_SIZE python3 tools/prof_ba.py c4 5 &&
 run_pmc match_fetch FETCH_SIZE python3 tools/prof_match.py 16 2 &&
 run_pmc match_write WRITE_SIZE python3 tools/prof_match.py 16 2 &&
-run_pmc match_mfma "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" python3 tools/prof_match.py 16 2
+run_pmc match_mfma "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" python3 tools/prof_match.py 16 2 &&
+run_pmc c2_valu "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" python3 tools/prof_ba.py c2 5 &&
+run_pmc c4_valu "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" python3 tools/prof_ba.py c4 5
 echo "profiles done rc=$?"
 # keep only the summaries (the raw per-dispatch traces are large)
 find $out -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +

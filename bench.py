@@ -315,7 +315,7 @@ def main():
             extra["tracking"] = bench_tracking(torch)
     if rank == 0:
         line = {
-            "metric": "BA observations/sec (residual+J+Schur)",
+            "metric": "BA observations/sec (residual+J+Schur) & SuperPoint matches/sec, 1\u20138 GPU",
             "value": ba["value"], "unit": "observations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ba["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -325,6 +325,9 @@ def main():
                 "precision": "fp64 values, int32 indices"},
             "roofline": ba["roofline"],
         }
+        if "matcher" in extra:   # second half of the metric: SuperPoint query rows matched per second
+            line["matcher_value"] = extra["matcher"]["query_rows_per_s"]
+            line["matcher_unit"] = "query rows/s (64 pairs of 4096 x 4096, mutual check)"
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         elif not args.no_cpu:

@@ -175,100 +175,317 @@ syrk_update_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int k0, int 
         }
 }
 
-// Whole factorisation in ONE workgroup (1024 threads) for systems whose trailing window is
-// narrow (band) or small (few cameras): per 32-column panel, the workgroup factors the diagonal
-// block, one thread per row forms the panel X = A_panel * L_kk^-T by forward substitution into
-// LDS, and all threads apply the trailing update to the bw x bw window.  No launches between
-// panels; the window lives in L2.  The block inverses the triangular solves use are formed
-// afterwards for all panels at once (trinv_panels_kernel).
-constexpr int kFusedMaxRows = 448;   // panel rows held in LDS (>= min(bw, n))
+// ---------------------------------------------------------------------------------------------
+// Single-workgroup factorisation and solve for systems whose trailing window is narrow (band) or
+// small (few cameras).  Matrix products run on the fp64 matrix cores:
+// v_mfma_f64_16x16x4_f64, lane l holds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15],
+// the result registers hold D[row (l >> 4) + 4 v][col l & 15], v = 0..3.  A 32-deep product takes 8
+// instructions; the order in which k is consumed is free as long as both operands agree, so lane
+// (l15, lk) takes k = 8 lk + s in step s and fetches its 8 values as four 16-byte LDS reads.
+constexpr int kFusedMaxRows = 448;   // widest trailing window (rows below the diagonal block)
+constexpr int kXS = 34;              // LDS row stride in doubles: 16-byte aligned rows, and the
+                                     // 16 rows of one operand read start 4 banks apart
+constexpr int kWin = 512;            // circular LDS window of the right-hand side (>= 448 + 32)
+typedef double d4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(1024)
-chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restrict__ info)
+__device__ __forceinline__ void load_frag(const real *row, int lk, real *f)
 {
-    __shared__ real W[kNB][kNB + 1];
-    __shared__ real F[kNB][kNB + 1];
-    __shared__ real invd[kNB];
+    const double2 *p = reinterpret_cast<const double2 *>(row + 8 * lk);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const double2 v = p[q]; f[2 * q] = v.x; f[2 * q + 1] = v.y; }
+}
+
+// 16 x 16 tile of  P Q^T  over k = 0..31 from two fragments (two accumulators, summed at the end)
+__device__ __forceinline__ d4 frag_product(const real *a, const real *b)
+{
+    d4 e = { 0, 0, 0, 0 }, o = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], e, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b[s + 1], o, 0, 0, 0);
+    }
+    return e + o;
+}
+
+// Column j of the 32 x 32 block has received its last update: its 32 owners (one half-wave, lane
+// bi = row) read the pivot from the diagonal owner's lane, scale the column by 1 / sqrt(pivot) and
+// publish the finished factor column (zero above the diagonal).  A non-positive pivot is
+// recorded (first one wins) and replaced by 1.  Returns the owner's factor entry L[bi][j].
+__device__ __forceinline__ real publish_column(real w, int j, int bi, int lane, int k0,
+                                               real *__restrict__ col, real *__restrict__ rsv,
+                                               int *__restrict__ bad)
+{
+    const int src = (lane & 32) | j;
+    real d = __shfl(w, src, 64);
+    if (!(d > real(0))) {
+        if (bi == j && *bad == 0) *bad = k0 + j + 1;
+        d = real(1);
+        if (bi == j) w = real(1);
+    }
+    const real rs = rsqrt_refined(d);
+    const real l = bi >= j ? w * rs : real(0);
+    col[bi] = l;
+    if (bi == j) rsv[j] = rs;
+    return l;
+}
+
+// Per 32-column panel:
+//   1. the diagonal block goes to registers (one element per thread), the panel rows below it to
+//      LDS (zero outside the band and beyond the matrix);
+//   2. 32 column steps, one barrier each, factor the block and invert the factor: a step reads the
+//      finished column c (published by its owners in the previous step) and the reciprocal square
+//      root of its pivot (computed by the pivot's owner alone), updates the columns to its right in
+//      registers, and advances the forward substitution F Y = I by one row;
+//   3. X = A_panel * L_kk^-T  on the matrix cores (one 16-row tile per wave and turn);
+//   4. trailing update of the bw x bw window, 16 x 16 tiles of the lower triangle dealt to the
+//      16 waves.
+// No launches between panels; the window lives in L2.  The block inverses are kept for the
+// triangular solves.
+__global__ void __launch_bounds__(1024)
+chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restrict__ info,
+                  real *__restrict__ Linv)
+{
+    __shared__ real colb[kNB][kNB];                              // colb[c][i] = column c, row i, final
+    __shared__ __attribute__((aligned(16))) real Li[kNB][kXS];    // inverse of the block's factor
+    __shared__ real rsv[kNB];                                     // 1 / sqrt(pivot c)
+    __shared__ int bad_s;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    real (*X)[kNB + 1] = reinterpret_cast<real (*)[kNB + 1]>(dyn_lds);
+    real (*X)[kXS] = reinterpret_cast<real (*)[kXS]>(dyn_lds);
     const int tid = threadIdx.x;
-    const int bi = tid / kNB, bj = tid % kNB;
+    const int bi = tid % kNB, bj = tid / kNB;
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
+    if (tid == 0) bad_s = 0;
     for (int k0 = 0; k0 < n; k0 += kNB) {
         const int nb = min(kNB, n - k0);
-        W[bi][bj] = (bi < nb && bj <= bi) ? A[(int64_t)(k0 + bi) * ld + k0 + bj] : (bi == bj ? real(1) : real(0));
-        F[bi][bj] = real(0);
-        __syncthreads();
-        const int bad = potrf32_block(W, F, nb, bi, bj);
-        if (bad && tid == 0 && *info == 0) *info = k0 + bad;
-        if (bi < nb && bj <= bi) A[(int64_t)(k0 + bi) * ld + k0 + bj] = F[bi][bj];
-        if (tid < kNB) invd[tid] = tid < nb ? real(1) / F[tid][tid] : real(1);
-        __syncthreads();
         const int base = k0 + nb;
-        const int rem = min(n - base, bw);
-        if (rem <= 0) break;                         // uniform: last panel
-        // panel row r: x[c] = (a[c] - sum_{m < c} x[m] F[c][m]) / F[c][c]; out-of-band a[m] = 0
-        if (tid < rem) {
-            const int i = base + tid;
-            const real *row = A + (int64_t)i * ld + k0;
-            const int m_lo = max(0, i - k0 - bw);
-            real *xr = X[tid];                       // the thread's own LDS row
-            for (int c = 0; c < kNB; c++) {
-                const bool in = c >= m_lo && c < nb;
-                xr[c] = in ? row[c] : real(0);
+        const int rem = max(0, min(n - base, bw));
+        const int nrt = (rem + 15) >> 4;                          // 16-row tiles of the panel
+        real *Lp = Linv + (int64_t)(k0 / kNB) * kNB * kNB;
+#ifdef VS_CHOL_TIMING
+        unsigned long long st0 = __builtin_readcyclecounter();
+#endif
+        // 1. thread (bi, bj) owns element (bi, bj) of the block (identity beyond nb); a column is one
+        //    half-wave, so its pivot reaches the column's 32 owners by a lane read
+        real w = (bi < nb && bj <= bi) ? A[(int64_t)(k0 + bi) * ld + k0 + bj] : (bi == bj ? real(1) : real(0));
+        real y = bi == bj ? real(1) : real(0);                    // forward substitution on I
+        real f = real(0), la_prev = real(0);
+        if (bj == 0) f = publish_column(w, 0, bi, lane, k0, colb[0], rsv, &bad_s);
+        for (int e = tid; e < nrt * 16 * kNB; e += 1024) {
+            const int r = e / kNB, c = e % kNB;
+            const int i = base + r;
+            X[r][c] = (r < rem && c < nb && i - (k0 + c) <= bw) ? A[(int64_t)i * ld + k0 + c] : real(0);
+        }
+        __syncthreads();
+#ifdef VS_CHOL_TIMING
+        unsigned long long st1 = __builtin_readcyclecounter();
+#endif
+        // 2. column steps
+        for (int c = 0; c < kNB; c++) {
+            const real la = colb[c][bi], lb = colb[c][bj];        // L[bi][c], L[bj][c]
+            if (bj > c && bj <= bi) w = fma(-la, lb, w);
+            if (bj == c + 1) f = publish_column(w, c + 1, bi, lane, k0, colb[c + 1], rsv, &bad_s);
+            if (c >= 1 && bi >= c) y = fma(-la_prev, Li[c - 1][bj], y);
+            if (bi == c) {                                        // row c of the inverse is final
+                const real x = y * rsv[c];
+                Li[c][bj] = x;
+                Lp[c * kNB + bj] = x;
             }
-            for (int c = 0; c < nb; c++) {
-                real sum = xr[c];
-                const real *fc = F[c];
-#pragma unroll 8
-                for (int m = 0; m < c; m++) sum = fma(-xr[m], fc[m], sum);
-                sum *= invd[c];
-                xr[c] = sum;
-                if (c >= m_lo) A[(int64_t)i * ld + k0 + c] = sum;
+            la_prev = la;
+            __syncthreads();
+        }
+#ifdef VS_CHOL_TIMING
+        unsigned long long st2 = __builtin_readcyclecounter();
+#endif
+        if (bi < nb && bj <= bi) A[(int64_t)(k0 + bi) * ld + k0 + bj] = f;
+        if (rem <= 0) break;                                      // uniform: last panel
+        // 3. X <- X * Li^T
+        {
+            real b0[8], b1[8];
+            load_frag(&Li[l15][0], lk, b0);
+            load_frag(&Li[16 + l15][0], lk, b1);
+            for (int ti = wave; ti < nrt; ti += 16) {
+                real a[8];
+                load_frag(&X[16 * ti + l15][0], lk, a);
+                const d4 p0 = frag_product(a, b0), p1 = frag_product(a, b1);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * ti + lk + 4 * v;
+                    X[r][l15] = p0[v];
+                    X[r][16 + l15] = p1[v];
+                    const int i = base + r;
+                    if (r < rem) {
+                        if (l15 < nb && i - (k0 + l15) <= bw) A[(int64_t)i * ld + k0 + l15] = p0[v];
+                        if (16 + l15 < nb && i - (k0 + 16 + l15) <= bw) A[(int64_t)i * ld + k0 + 16 + l15] = p1[v];
+                    }
+                }
             }
         }
         __syncthreads();
-        // trailing update, 4 x 4 outputs per thread over 64 x 64 tiles of the lower triangle
-        const int nt = (rem + kTile - 1) / kTile;
-        const int n_tiles = nt * (nt + 1) / 2;
-        const int sub = tid & 255, ty = sub / 16, tx = sub % 16;
-        for (int t = tid >> 8; t < n_tiles; t += 4) {
-            int ti = 0, acc_t = 0;
-            while (acc_t + ti + 1 <= t) { acc_t += ti + 1; ti++; }
-            const int tj = t - acc_t;
-            real acc[4][4];
+#ifdef VS_CHOL_TIMING
+        unsigned long long st3 = __builtin_readcyclecounter();
+#endif
+        // 4. trailing update
+        const int n_tiles = nrt * (nrt + 1) / 2;
+        {
+            // tile t of the lower triangle -> (ti, tj); the old values of a tile are fetched one
+            // turn ahead of its product
+            auto fetch = [&](int t, int &ti, int &tj, real *old, bool *ok) {
+                ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (ti * (ti + 1) / 2 > t) ti--;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+                tj = t - ti * (ti + 1) / 2;
+                const int cc = 16 * tj + l15;
 #pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) acc[a][b] = real(0);
-            int ri[4], rj[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                ri[a] = min(ti * kTile + ty + 16 * a, rem - 1);
-                rj[a] = min(tj * kTile + tx + 16 * a, rem - 1);
-            }
-#pragma unroll 4
-            for (int m = 0; m < kNB; m++) {
-                real xi[4], xj[4];
-#pragma unroll
-                for (int a = 0; a < 4; a++) { xi[a] = X[ri[a]][m]; xj[a] = X[rj[a]][m]; }
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++) acc[a][b] = fma(xi[a], xj[b], acc[a][b]);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int r = ti * kTile + ty + 16 * a, c = tj * kTile + tx + 16 * b;
-                    if (r < rem && c <= r) A[(int64_t)(base + r) * ld + base + c] -= acc[a][b];
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * ti + lk + 4 * v;
+                    ok[v] = r < rem && cc <= r;
+                    old[v] = ok[v] ? A[(int64_t)(base + r) * ld + base + cc] : real(0);
                 }
+            };
+            int t = wave, ti = 0, tj = 0;
+            real old[4] = { 0, 0, 0, 0 };
+            bool ok[4] = { false, false, false, false };
+            if (t < n_tiles) fetch(t, ti, tj, old, ok);
+            while (t < n_tiles) {
+                real a[8], b[8];
+                load_frag(&X[16 * ti + l15][0], lk, a);
+                load_frag(&X[16 * tj + l15][0], lk, b);
+                const int tn = t + 16;
+                int tin = 0, tjn = 0;
+                real oldn[4] = { 0, 0, 0, 0 };
+                bool okn[4] = { false, false, false, false };
+                if (tn < n_tiles) fetch(tn, tin, tjn, oldn, okn);
+                const d4 p = frag_product(a, b);
+                const int cc = 16 * tj + l15;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * ti + lk + 4 * v;
+                    if (ok[v]) A[(int64_t)(base + r) * ld + base + cc] = old[v] - p[v];
+                }
+                t = tn; ti = tin; tj = tjn;
+#pragma unroll
+                for (int v = 0; v < 4; v++) { old[v] = oldn[v]; ok[v] = okn[v]; }
+            }
         }
+        __syncthreads();
+#ifdef VS_CHOL_TIMING
+        unsigned long long st4 = __builtin_readcyclecounter();
+        if (tid == 0 && k0 == 32 * 3) printf("panel: load %llu steps %llu product %llu trailing %llu rem %d\n", st1 - st0, st2 - st1, st3 - st2, st4 - st3, rem);
+#endif
+    }
+    if (tid == 0 && bad_s && *info == 0) *info = bad_s;
+}
+
+// Sum over the 16 lanes of a DPP row, result in every lane of the row.
+template <int CTRL>
+__device__ __forceinline__ real dpp_move(real v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ real sum32(real v)
+{
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    v += __shfl_xor(v, 16, 64);  // the other row of this 32-lane half
+    return v;
+}
+
+// Solve L y = b then L^T x = y in place for the narrow-window case (single workgroup, 1024
+// threads = 32 x 32).  Linv holds the inverse of every 32 x 32 diagonal block of L, so a block
+// solve is a 32 x 32 matrix-vector product: thread (r, m) multiplies one element and the 32 lanes
+// of a row add up.  The active part of the right-hand side lives in a circular LDS window; block
+// inverses and factor rows, which do not depend on the right-hand side, are fetched before the
+// dependent work of a panel starts.
+__global__ void __launch_bounds__(1024)
+chol_trsv_window_kernel(const real *__restrict__ A, int n, int64_t ld, int bw,
+                        const real *__restrict__ Linv, real *__restrict__ b)
+{
+    __shared__ real win[kWin];
+    __shared__ real ys[kNB];
+    const int tid = threadIdx.x;
+    const int r32 = tid / kNB, m = tid % kNB;
+    const int wave = tid >> 6, half = (tid >> 5) & 1;
+    const int reach = kNB + min(bw, n);                            // rows a panel touches
+    constexpr int kMaxQ = kFusedMaxRows / 32;
+    // ---- forward: L y = b
+    for (int i = tid; i < min(n, reach); i += 1024) win[i & (kWin - 1)] = b[i];
+    real li = Linv[r32 * kNB + m];
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += kNB) {
+        const int nb = min(kNB, n - k0);
+        const int base = k0 + nb;
+        const int rem = max(0, min(n - base, bw));
+        // factor rows of this panel (2 rows per wave and turn, lanes along the 32 columns)
+        real av[kMaxQ];
+#pragma unroll
+        for (int q = 0; q < kMaxQ; q++) {
+            const int r = 2 * (wave + 16 * q) + half, i = base + r;
+            av[q] = (r < rem && m < nb && i - (k0 + m) <= bw) ? A[(int64_t)i * ld + k0 + m] : real(0);
+        }
+        const real bp = k0 + m < n ? win[(k0 + m) & (kWin - 1)] : real(0);
+        const real yv = sum32(li * bp);                            // (Linv b_panel)[r32]
+        if (m == 0) { ys[r32] = yv; if (r32 < nb) b[k0 + r32] = yv; }
+        if (k0 + kNB < n) li = Linv[(int64_t)(k0 / kNB + 1) * kNB * kNB + r32 * kNB + m];
+        real incoming = real(0);
+        const int irow = k0 + reach + tid;
+        if (tid < kNB && irow < n) incoming = b[irow];
+        __syncthreads();
+        const real ym = ys[m];
+#pragma unroll
+        for (int q = 0; q < kMaxQ; q++) {
+            const int r = 2 * (wave + 16 * q) + half;
+            if (2 * (16 * q) < rem) {                              // uniform over the workgroup
+                const real s = sum32(av[q] * ym);
+                if (m == 0 && r < rem) win[(base + r) & (kWin - 1)] -= s;
+            }
+        }
+        if (tid < kNB && irow < n) win[irow & (kWin - 1)] = incoming;
+        __syncthreads();
+    }
+    // ---- backward: L^T x = y
+    const int k_last = ((n - 1) / kNB) * kNB;
+    for (int i = max(0, k_last - bw) + tid; i < n; i += 1024) win[i & (kWin - 1)] = b[i];
+    li = Linv[(int64_t)(k_last / kNB) * kNB * kNB + m * kNB + r32];   // transposed element
+    __syncthreads();
+    for (int k0 = k_last; k0 >= 0; k0 -= kNB) {
+        const int nb = min(kNB, n - k0);
+        const int lo = max(0, k0 - bw);
+        // thread (row, column half): the two halves of the 1024 threads split the 32 columns
+        const int i = lo + (tid & 511), ch = tid >> 9;
+        const bool mine = i < k0;
+        real av[kNB / 2];
+#pragma unroll
+        for (int q = 0; q < kNB / 2; q++) {
+            const int c = 16 * ch + q;
+            av[q] = (mine && c < nb && k0 + c - i <= bw) ? A[(int64_t)(k0 + c) * ld + i] : real(0);
+        }
+        const real bp = k0 + m < n ? win[(k0 + m) & (kWin - 1)] : real(0);
+        const real xv = sum32(li * bp);                            // (Linv^T b_panel)[r32]
+        if (m == 0) { ys[r32] = xv; if (r32 < nb) b[k0 + r32] = xv; }
+        if (k0 > 0) li = Linv[(int64_t)(k0 / kNB - 1) * kNB * kNB + m * kNB + r32];
+        real incoming = real(0);
+        const int irow = k0 - kNB - bw + tid;                      // rows entering the next window
+        const bool take = tid < kNB && irow >= 0 && irow < lo;
+        if (take) incoming = b[irow];
+        __syncthreads();
+        real s = real(0);
+#pragma unroll
+        for (int q = 0; q < kNB / 2; q++) s = fma(av[q], ys[16 * ch + q], s);
+        if (mine && ch == 0) win[i & (kWin - 1)] -= s;            // fixed order: low columns first
+        __syncthreads();
+        if (mine && ch == 1) win[i & (kWin - 1)] -= s;
+        if (take) win[irow & (kWin - 1)] = incoming;
         __syncthreads();
     }
 }
 
-// Solve L y = b then L^T x = y in place (single workgroup, 1024 threads), L = lower of A.
+// Solve L y = b then L^T x = y in place for wide windows (single workgroup, 1024 threads); the
+// right-hand side stays in global memory.
 // Linv holds the inverse of every 32 x 32 diagonal block of L (panel p at Linv + 1024 p), so a
 // block solve is a 32 x 32 matrix-vector product.
 __global__ void __launch_bounds__(1024)
@@ -391,33 +608,34 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
 {
     const int window = bw < n ? bw : n;
     if (window <= kFusedMaxRows) {
-        const size_t lds = (size_t)window * (kNB + 1) * sizeof(real);
+        const size_t lds = (size_t)((window + 15) & ~15) * kXS * sizeof(real);
         static bool lds_limit_raised = false;     // dynamic LDS beyond the default limit
         if (!lds_limit_raised) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kFusedMaxRows * (kNB + 1) * (int)sizeof(real)) != hipSuccess) {
+                                    kFusedMaxRows * kXS * (int)sizeof(real)) != hipSuccess) {
                 set_error("cannot raise the dynamic LDS limit of the fused Cholesky kernel");
                 return VS_ERR_HIP;
             }
             lds_limit_raised = true;
         }
-        hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(1024), lds, s, A, n, ld, bw, info);
-        hipLaunchKernelGGL(trinv_panels_kernel, dim3((n + kNB - 1) / kNB), dim3(kNB * kNB), 0, s, A, n, ld, Linv);
-    } else
-    for (int k0 = 0; k0 < n; k0 += kNB) {
-        const int nb = n - k0 < kNB ? n - k0 : kNB;
-        real *Lp = Linv + (int64_t)(k0 / kNB) * kNB * kNB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(kNB * kNB), 0, s, A, ld, k0, nb, info, Lp);
-        int rem = n - k0 - nb;
-        if (rem > bw) rem = bw;   // rows further down hold no in-band element of this panel
-        if (rem > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + kNB - 1) / kNB), dim3(kNB, kNB), 0, s, A, n, ld, bw, k0, nb, Lp);
-            const int nt = (rem + kTile - 1) / kTile;
-            hipLaunchKernelGGL(syrk_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, n, ld, bw, k0, nb);
+        hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(1024), lds, s, A, n, ld, bw, info, Linv);
+        hipLaunchKernelGGL(chol_trsv_window_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
+    } else {
+        for (int k0 = 0; k0 < n; k0 += kNB) {
+            const int nb = n - k0 < kNB ? n - k0 : kNB;
+            real *Lp = Linv + (int64_t)(k0 / kNB) * kNB * kNB;
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(kNB * kNB), 0, s, A, ld, k0, nb, info, Lp);
+            int rem = n - k0 - nb;
+            if (rem > bw) rem = bw;   // rows further down hold no in-band element of this panel
+            if (rem > 0) {
+                hipLaunchKernelGGL(trsm_panel_kernel, dim3((rem + kNB - 1) / kNB), dim3(kNB, kNB), 0, s, A, n, ld, bw, k0, nb, Lp);
+                const int nt = (rem + kTile - 1) / kTile;
+                hipLaunchKernelGGL(syrk_update_kernel, dim3(nt, nt), dim3(256), 0, s, A, n, ld, bw, k0, nb);
+            }
         }
+        hipLaunchKernelGGL(chol_trsv_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
     }
-    hipLaunchKernelGGL(chol_trsv_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("Cholesky launch failed: %s", hipGetErrorString(e));

@@ -237,6 +237,18 @@ int vs_compute_points3d(const float *desc0, const int32_t *xy0, int32_t n0, cons
                         const int32_t *xy1, int32_t n1, const float *K4, float baseline_fx,
                         const float *pose, uint8_t *good, float *xyz, int32_t *minloc);
 
+/* Tracking::updateTrackedPoints (src/core/tracking.cc:378-451): two-view linear triangulation of
+ * every tracked point seen in both the oldest (pose1, key_xy1, tracks1) and the newest (pose2,
+ * key_xy2, tracks2) frame of the window.  tracks*[i] = keypoint index or -1.  A point is
+ * re-triangulated when the rays' parallax cosine lies in [0, 0.9998] and the new point has depth
+ * (camera +Y) > 0.2 in both frames; then xyz[3i..3i+2] is overwritten and updated[i] = 1
+ * (updated may be NULL).  The float 4 x 4 system is built as the reference builds it; its null
+ * vector (JacobiSVD::matrixV().col(3) in the reference, float) is computed in double. */
+int vs_triangulate_tracks(const float *pose1, const float *pose2, const float *K4,
+                          const int32_t *key_xy1, int32_t n_keys1, const int32_t *tracks1,
+                          const int32_t *key_xy2, int32_t n_keys2, const int32_t *tracks2,
+                          int32_t n_tp, float *xyz, uint8_t *updated, int32_t *n_updated);
+
 #ifdef __cplusplus
 }
 #endif

@@ -270,3 +270,25 @@ def compute_points3d(d0, xy0, d1, xy1, K4f, bf, pose):
     lib().vo_compute_points3d(_f(d0), _i(xy0), len(d0), _f(d1), _i(xy1), len(d1), _f(_f32(K4f)),
                               C.c_float(bf), _f(_f32(pose)), good.ctypes.data_as(c_bp), _f(Pw), _i(loc))
     return good, Pw, loc
+
+
+def dlt_system(pose1, pose2, K4f, key1, key2):
+    """The float 4 x 4 system updateTrackedPoints builds for one track, or None when the
+    parallax gate rejects the pair of rays."""
+    A = np.zeros(16, np.float32)
+    ok = np.zeros(1, np.int32)
+    lib().vo_dlt_system(_f(_f32(pose1)), _f(_f32(pose2)), _f(_f32(K4f)), _i(_i32(key1)), _i(_i32(key2)),
+                        _f(A), _i(ok))
+    return A.reshape(4, 4) if ok[0] else None
+
+
+def triangulate_tracks(pose1, pose2, K4f, keys1, tracks1, keys2, tracks2, xyz):
+    """Tracking::updateTrackedPoints.  Returns (xyz, updated, n_updated)."""
+    keys1, keys2 = _i32(keys1).reshape(-1, 2), _i32(keys2).reshape(-1, 2)
+    tracks1, tracks2 = _i32(tracks1), _i32(tracks2)
+    Pw = _f32(xyz).reshape(-1, 3).copy()
+    upd = np.zeros(len(Pw), np.uint8)
+    lib().vo_triangulate_tracks.restype = C.c_int
+    n = lib().vo_triangulate_tracks(_f(_f32(pose1)), _f(_f32(pose2)), _f(_f32(K4f)), _i(keys1), _i(tracks1),
+                                    _i(keys2), _i(tracks2), len(Pw), _f(Pw), upd.ctypes.data_as(c_bp))
+    return Pw, upd, n

@@ -1,7 +1,8 @@
 /*
  * TEST INFRASTRUCTURE ONLY.  CPU restatement of the per-frame tracking helpers that sit beside
  * the matcher and the optimiser in scomup/visual_slam (reference paths are relative to the
- * reference tree): Tracking::reprojection, Tracking::removeOutlier, Frame::computePoint3d.
+ * reference tree): Tracking::reprojection, Tracking::removeOutlier, Frame::computePoint3d,
+ * Tracking::updateTrackedPoints.
  *
  * PARITY UNPINNED: the reference holds no tests or golden vectors for these functions and needs
  * Eigen / OpenCV (absent here) to build.  The float arithmetic is restated from Eigen's
@@ -161,4 +162,144 @@ void vo_compute_points3d(const float *d0, const int32_t *xy0, int n0, const floa
         rigid_apply_f(inv_pose, v, Pw + 3 * (size_t)i);
         good[i] = 1;
     }
+}
+
+/* ---- Tracking::updateTrackedPoints (tracking.cc:378-451): two-view linear triangulation --------
+ * Float construction restated operation by operation; Eigen details (version unpinned):
+ *   - Quaternionf::normalized() = coeffs / sqrt(squaredNorm); the 4-term sum is taken as
+ *     (x^2 + y^2) + (z^2 + w^2) (Eigen's packet reduction order is not pinned by the reference)
+ *   - toRotationMatrix(): tx = 2x, ty = 2y, tz = 2z; twx = tx w ...; R00 = 1 - (tyy + tzz) ...
+ *   - Quaternionf::inverse() = conjugate coefficients / squaredNorm
+ *   - 3-vector dot and squaredNorm sum left to right
+ * The null vector of the 4 x 4 system is what Eigen::JacobiSVD<Matrix4f>::matrixV().col(3) holds up
+ * to sign and float round-off.  Here it is the eigenvector of the smallest eigenvalue of A^T A by
+ * cyclic Jacobi rotations in double (the float SVD of the reference agrees to the conditioning of
+ * the system times float epsilon). */
+static void quat_to_rot_f(const float *q /* w x y z */, float *R /* 9 row-major */)
+{
+    const float n = sqrtf((q[1] * q[1] + q[2] * q[2]) + (q[3] * q[3] + q[0] * q[0]));
+    const float w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0f - (txx + tyy);
+}
+
+static void quat_inverse_f(const float *q, float *o)
+{
+    const float n2 = (q[1] * q[1] + q[2] * q[2]) + (q[3] * q[3] + q[0] * q[0]);
+    o[0] = q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = -q[3] / n2;
+}
+
+/* unit eigenvector of the smallest eigenvalue of the symmetric 4 x 4 matrix B (destroyed) */
+static void smallest_eigvec4(double B[4][4], double *v)
+{
+    double V[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int p = 0; p < 4; p++) {
+            diag += B[p][p] * B[p][p];
+            for (int q = p + 1; q < 4; q++) off += B[p][q] * B[p][q];
+        }
+        if (off <= 1e-60 || off <= 1e-34 * diag) break;
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                if (B[p][q] == 0.0) continue;
+                const double theta = (B[q][q] - B[p][p]) / (2.0 * B[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 4; k++) {
+                    const double bkp = B[k][p], bkq = B[k][q];
+                    B[k][p] = c * bkp - s * bkq; B[k][q] = s * bkp + c * bkq;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double bpk = B[p][k], bqk = B[q][k];
+                    B[p][k] = c * bpk - s * bqk; B[q][k] = s * bpk + c * bqk;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int p = 1; p < 4; p++) if (B[p][p] < B[m][m]) m = p;
+    for (int k = 0; k < 4; k++) v[k] = V[k][m];
+}
+
+/* The 4 x 4 system of one track (float), or 0 when the parallax gate rejects it. */
+static int dlt_system_f(const float *pose1, const float *pose2, const float *K4, const int32_t *key1,
+                        const int32_t *key2, float A[4][4])
+{
+    float M1[3][4], M2[3][4], R[9];
+    quat_to_rot_f(pose1 + 3, R);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M1[r][c] = R[3 * r + c]; M1[r][3] = pose1[r]; }
+    quat_to_rot_f(pose2 + 3, R);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M2[r][c] = R[3 * r + c]; M2[r][3] = pose2[r]; }
+    const float invfx = 1.0f / K4[0], invfy = 1.0f / K4[1];
+    const float xn1[3] = { ((float)key1[0] - K4[2]) * invfx, 1.0f, -((float)key1[1] - K4[3]) * invfy };
+    const float xn2[3] = { ((float)key2[0] - K4[2]) * invfx, 1.0f, -((float)key2[1] - K4[3]) * invfy };
+    float qi[4], ray1[3], ray2[3];
+    quat_inverse_f(pose1 + 3, qi); quat_rotate_f(qi, xn1, ray1);
+    quat_inverse_f(pose2 + 3, qi); quat_rotate_f(qi, xn2, ray2);
+    const float dot = (ray1[0] * ray2[0] + ray1[1] * ray2[1]) + ray1[2] * ray2[2];
+    const float n1 = sqrtf((ray1[0] * ray1[0] + ray1[1] * ray1[1]) + ray1[2] * ray1[2]);
+    const float n2 = sqrtf((ray2[0] * ray2[0] + ray2[1] * ray2[1]) + ray2[2] * ray2[2]);
+    const float cosp = dot / (n1 * n2);
+    if (cosp < 0 || (double)cosp > 0.9998) return 0;
+    for (int c = 0; c < 4; c++) {
+        A[0][c] = xn1[0] * M1[1][c] - M1[0][c];
+        A[1][c] = xn1[2] * M1[1][c] - M1[2][c];
+        A[2][c] = xn2[0] * M2[1][c] - M2[0][c];
+        A[3][c] = xn2[2] * M2[1][c] - M2[2][c];
+    }
+    return 1;
+}
+
+void vo_dlt_system(const float *pose1, const float *pose2, const float *K4, const int32_t *key1,
+                   const int32_t *key2, float *A16, int32_t *ok)
+{
+    float A[4][4] = { { 0 } };
+    *ok = dlt_system_f(pose1, pose2, K4, key1, key2, A);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) A16[4 * r + c] = A[r][c];
+}
+
+/* Pw[3i..] is overwritten and updated[i] = 1 where the reference assigns tracked_points_[i]->Pw.
+ * pose1/keys1/tracks1 = oldest frame of the window, pose2/keys2/tracks2 = newest.  Returns the
+ * number of points updated. */
+int vo_triangulate_tracks(const float *pose1, const float *pose2, const float *K4,
+                          const int32_t *keys1, const int32_t *tracks1, const int32_t *keys2,
+                          const int32_t *tracks2, int n_tp, float *Pw, uint8_t *updated)
+{
+    int cont = 0;
+    for (int i = 0; i < n_tp; i++) {
+        updated[i] = 0;
+        const int id1 = tracks1[i], id2 = tracks2[i];
+        if (id1 == -1 || id2 == -1) continue;
+        float A[4][4];
+        if (!dlt_system_f(pose1, pose2, K4, keys1 + 2 * (size_t)id1, keys2 + 2 * (size_t)id2, A)) continue;
+        double B[4][4], v[4];
+        for (int p = 0; p < 4; p++)
+            for (int q = 0; q < 4; q++) {
+                double s = 0;
+                for (int k = 0; k < 4; k++) s += (double)A[k][p] * (double)A[k][q];
+                B[p][q] = s;
+            }
+        smallest_eigvec4(B, v);
+        const float x3[4] = { (float)v[0], (float)v[1], (float)v[2], (float)v[3] };
+        if (x3[3] == 0) continue;
+        const float P[3] = { x3[0] / x3[3], x3[1] / x3[3], x3[2] / x3[3] };
+        float Pc[3];
+        rigid_apply_f(pose1, P, Pc);
+        if ((double)Pc[1] <= 0.2) continue;
+        rigid_apply_f(pose2, P, Pc);
+        if ((double)Pc[1] <= 0.2) continue;
+        Pw[3 * (size_t)i] = P[0]; Pw[3 * (size_t)i + 1] = P[1]; Pw[3 * (size_t)i + 2] = P[2];
+        updated[i] = 1;
+        cont++;
+    }
+    return cont;
 }

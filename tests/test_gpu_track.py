@@ -104,3 +104,40 @@ def test_empty_inputs():
     assert np.array_equal(t, -np.ones(4, np.int32))
     g, p, l = vt.compute_points3d(np.ones((3, 256)), np.zeros((3, 2)), np.zeros((0, 256)), np.zeros((0, 2)), K4, 20.0, pose)
     assert not g.any() and np.array_equal(l, -np.ones(3, np.int32))
+
+
+@pytest.mark.parametrize("n_tp,seed", [(1, 0), (333, 1), (5000, 2)])
+def test_triangulate_tracks_matches_oracle(orc, n_tp, seed):
+    """updateTrackedPoints: the float construction and the gates are replayed identically, the
+    null vector comes from two different fp64 Jacobi methods (device: one-sided on A; oracle:
+    eigenvectors of A^T A), so points agree to float rounding of the result (tolerance 2e-6
+    relative); a point whose depth sits within 1e-4 of the 0.2 gate may legitimately flip."""
+    pose1, pose2, K4, keys1, tracks1, keys2, tracks2, xyz0 = synth.make_two_view_tracks(n_tp, seed=seed)
+    want_p, want_u, want_n = orc.triangulate_tracks(pose1, pose2, K4, keys1, tracks1, keys2, tracks2, xyz0)
+    got_p, got_u, got_n = vt.triangulate_tracks(pose1, pose2, K4, keys1, tracks1, keys2, tracks2, xyz0)
+    diff = np.flatnonzero(got_u != want_u)
+    for i in diff:                                                # only gate-boundary cases may differ
+        P = got_p[i] if got_u[i] else want_p[i]
+        ys = [orc.rigid_apply(pose1, P)[1], orc.rigid_apply(pose2, P)[1]]
+        assert min(abs(y - 0.2) for y in ys) < 1e-4, i
+    assert len(diff) <= max(1, n_tp // 500)
+    both = (got_u == 1) & (want_u == 1)
+    assert got_n == int(got_u.sum())
+    if n_tp > 100:
+        assert both.sum() > n_tp // 3
+    np.testing.assert_allclose(got_p[both], want_p[both], rtol=2e-6, atol=2e-6)
+    same = (got_u == 0) & (want_u == 0)
+    assert np.array_equal(bits(got_p[same]), bits(xyz0[same]))
+
+
+def test_triangulate_tracks_empty_and_untracked():
+    pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    K4 = np.array([170.5, 170.5, 191.5, 103.4], np.float32)
+    p, u, n = vt.triangulate_tracks(pose, pose, K4, np.zeros((0, 2)), np.zeros(0), np.zeros((0, 2)), np.zeros(0), np.zeros((0, 3)))
+    assert len(p) == 0 and n == 0
+    xyz = np.ones((5, 3), np.float32)
+    p, u, n = vt.triangulate_tracks(pose, pose, K4, np.zeros((3, 2)), -np.ones(5), np.zeros((3, 2)), -np.ones(5), xyz)
+    assert n == 0 and not u.any() and np.array_equal(p, xyz)
+    # identical poses: zero parallax (cosine 1 > 0.9998) -> nothing is updated
+    p, u, n = vt.triangulate_tracks(pose, pose, K4, np.full((3, 2), 100), np.arange(3), np.full((3, 2), 100), np.arange(3), xyz[:3])
+    assert n == 0 and not u.any()

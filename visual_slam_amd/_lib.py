@@ -25,6 +25,7 @@ SYMBOLS = [
     "vs_matcher_run", "vs_matcher_get_matches", "vs_matcher_get_nn", "vs_matcher_get_rescans",
     "vs_match_two_way", "vs_match_stereo",
     "vs_reproject_points", "vs_search_projection", "vs_remove_outliers", "vs_compute_points3d",
+    "vs_triangulate_tracks",
 ]
 
 

@@ -1,6 +1,6 @@
 // Per-frame tracking helpers beside the matcher (reference interfaces: include/vslam_hip.h):
 // Tracking::reprojection / searchProjection / removeOutlier (src/core/tracking.cc:70-78,
-// 453-496, 346-377) and Frame::computePoint3d (src/core/frame.cc:45-86).
+// 453-496, 346-377, 378-451 updateTrackedPoints) and Frame::computePoint3d (src/core/frame.cc:45-86).
 //
 // The float geometry replays the reference's Eigen expressions operation by operation (every
 // product, sum and quotient rounded to float on its own: contraction into FMAs is switched off
@@ -368,6 +368,130 @@ points3d_kernel(Pose T, Intr4 K, float bf, const int2 *__restrict__ xy0, int n0,
     good[i] = 1;
 }
 
+// ---- Tracking::updateTrackedPoints (tracking.cc:378-451): two-view linear triangulation ---------
+// Eigen Quaternionf::normalized().toRotationMatrix() in float.
+__device__ __forceinline__ void quat_to_rot_f(const float *q, float *R)
+{
+    const float n = sqrtf((q[1] * q[1] + q[2] * q[2]) + (q[3] * q[3] + q[0] * q[0]));
+    const float w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0f - (txx + tyy);
+}
+
+// Eigen Quaternionf::inverse(): conjugate coefficients / squaredNorm
+__device__ __forceinline__ void quat_inverse_f(const float *q, float *o)
+{
+    const float n2 = (q[1] * q[1] + q[2] * q[2]) + (q[3] * q[3] + q[0] * q[0]);
+    o[0] = q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = -q[3] / n2;
+}
+
+// Right singular vector of the smallest singular value of the 4 x 4 matrix A (what
+// JacobiSVD::matrixV().col(3) holds up to sign), by one-sided Jacobi rotations on the columns of A
+// in double: the columns are made mutually orthogonal, V collects the rotations, and the column
+// of smallest norm marks the wanted column of V.
+__device__ __forceinline__ void null_vector4(double A[4][4], double *v)
+{
+    double V[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) V[r][c] = r == c ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double al = 0, be = 0, ga = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    al += A[k][p] * A[k][p]; be += A[k][q] * A[k][q]; ga += A[k][p] * A[k][q];
+                }
+                if (ga * ga > 1e-32 * al * be && ga != 0.0) {
+                    rotated = true;
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const double ap = A[k][p], aq = A[k][q];
+                        A[k][p] = c * ap - s * aq; A[k][q] = s * ap + c * aq;
+                        const double vp = V[k][p], vq = V[k][q];
+                        V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                    }
+                }
+            }
+        if (!rotated) break;
+    }
+    double best = 0;
+    int m = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        double nn = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) nn += A[k][c] * A[k][c];
+        if (c == 0 || nn < best) { best = nn; m = c; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = m == 0 ? V[k][0] : m == 1 ? V[k][1] : m == 2 ? V[k][2] : V[k][3];
+}
+
+// One thread per tracked point.
+__global__ void __launch_bounds__(128)
+triangulate_kernel(Pose T1, Pose T2, Intr4 K, const int2 *__restrict__ keys1, int n_keys1,
+                   const int *__restrict__ tracks1, const int2 *__restrict__ keys2, int n_keys2,
+                   const int *__restrict__ tracks2, int n_tp, float *__restrict__ Pw,
+                   unsigned char *__restrict__ updated, int *__restrict__ count)
+{
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= n_tp) return;
+    updated[i] = 0;
+    const int id1 = tracks1[i], id2 = tracks2[i];
+    if (id1 < 0 || id2 < 0 || id1 >= n_keys1 || id2 >= n_keys2) return;
+    float M1[3][4], M2[3][4], R[9];
+    quat_to_rot_f(T1.q, R);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M1[r][c] = R[3 * r + c]; M1[r][3] = T1.t[r]; }
+    quat_to_rot_f(T2.q, R);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M2[r][c] = R[3 * r + c]; M2[r][3] = T2.t[r]; }
+    const int2 k1 = keys1[id1], k2 = keys2[id2];
+    const float invfx = 1.0f / K.fx, invfy = 1.0f / K.fy;
+    const float xn1[3] = { ((float)k1.x - K.cx) * invfx, 1.0f, -((float)k1.y - K.cy) * invfy };
+    const float xn2[3] = { ((float)k2.x - K.cx) * invfx, 1.0f, -((float)k2.y - K.cy) * invfy };
+    float qi[4], ray1[3], ray2[3];
+    quat_inverse_f(T1.q, qi); quat_rotate_f(qi, xn1, ray1);
+    quat_inverse_f(T2.q, qi); quat_rotate_f(qi, xn2, ray2);
+    const float dot = (ray1[0] * ray2[0] + ray1[1] * ray2[1]) + ray1[2] * ray2[2];
+    const float n1 = sqrtf((ray1[0] * ray1[0] + ray1[1] * ray1[1]) + ray1[2] * ray1[2]);
+    const float n2 = sqrtf((ray2[0] * ray2[0] + ray2[1] * ray2[1]) + ray2[2] * ray2[2]);
+    const float cosp = dot / (n1 * n2);
+    if (cosp < 0 || (double)cosp > 0.9998) return;
+    double A[4][4];
+    for (int c = 0; c < 4; c++) {
+        A[0][c] = (double)(xn1[0] * M1[1][c] - M1[0][c]);
+        A[1][c] = (double)(xn1[2] * M1[1][c] - M1[2][c]);
+        A[2][c] = (double)(xn2[0] * M2[1][c] - M2[0][c]);
+        A[3][c] = (double)(xn2[2] * M2[1][c] - M2[2][c]);
+    }
+    double v[4];
+    null_vector4(A, v);
+    const float x3[4] = { (float)v[0], (float)v[1], (float)v[2], (float)v[3] };
+    if (x3[3] == 0) return;
+    const float P[3] = { x3[0] / x3[3], x3[1] / x3[3], x3[2] / x3[3] };
+    float Pc[3];
+    rigid_apply_f(T1, P, Pc);
+    if ((double)Pc[1] <= 0.2) return;
+    rigid_apply_f(T2, P, Pc);
+    if ((double)Pc[1] <= 0.2) return;
+    Pw[3 * (int64_t)i] = P[0]; Pw[3 * (int64_t)i + 1] = P[1]; Pw[3 * (int64_t)i + 2] = P[2];
+    updated[i] = 1;
+    atomicAdd(count, 1);
+}
+
 Pose make_pose(const float *p)
 {
     Pose T;
@@ -520,6 +644,44 @@ int vs_compute_points3d(const float *desc0, const int32_t *xy0, int32_t n0, cons
     VS_HIP(hipMemcpy(good, d_good.p, (size_t)n0, hipMemcpyDefault));
     VS_HIP(hipMemcpy(xyz, d_pw.p, (size_t)n0 * 3 * sizeof(float), hipMemcpyDefault));
     if (minloc) VS_HIP(hipMemcpy(minloc, d_loc.p, (size_t)n0 * sizeof(int), hipMemcpyDefault));
+    return VS_OK;
+}
+
+int vs_triangulate_tracks(const float *pose1, const float *pose2, const float *K4,
+                          const int32_t *key_xy1, int32_t n_keys1, const int32_t *tracks1,
+                          const int32_t *key_xy2, int32_t n_keys2, const int32_t *tracks2,
+                          int32_t n_tp, float *xyz, uint8_t *updated, int32_t *n_updated)
+{
+    VS_CHECK(pose1 && pose2 && K4 && n_tp >= 0 && n_keys1 >= 0 && n_keys2 >= 0, VS_ERR_INVALID, "bad arguments");
+    VS_CHECK(n_tp == 0 || (tracks1 && tracks2 && xyz), VS_ERR_INVALID, "null tracked-point arrays");
+    VS_CHECK((n_keys1 == 0 || key_xy1) && (n_keys2 == 0 || key_xy2), VS_ERR_INVALID, "null keypoint arrays");
+    if (n_updated) *n_updated = 0;
+    if (n_tp == 0) return VS_OK;
+    if (n_keys1 == 0 || n_keys2 == 0) {
+        if (updated) for (int i = 0; i < n_tp; i++) updated[i] = 0;
+        return VS_OK;
+    }
+    VS_TRY(require_device());
+    DevBuf<float> d_xyz;
+    DevBuf<int2> d_k1, d_k2;
+    DevBuf<int> d_t1, d_t2, d_count;
+    DevBuf<unsigned char> d_upd;
+    VS_TRY(upload(d_xyz, xyz, (size_t)n_tp * 3));
+    VS_TRY(upload(d_k1, key_xy1, (size_t)n_keys1));
+    VS_TRY(upload(d_k2, key_xy2, (size_t)n_keys2));
+    VS_TRY(upload(d_t1, tracks1, (size_t)n_tp));
+    VS_TRY(upload(d_t2, tracks2, (size_t)n_tp));
+    VS_TRY(d_upd.alloc(n_tp)); VS_TRY(d_count.alloc(1));
+    VS_HIP(hipMemset(d_count.p, 0, sizeof(int)));
+    const Intr4 K{ K4[0], K4[1], K4[2], K4[3] };
+    hipLaunchKernelGGL(triangulate_kernel, dim3(div_up(n_tp, 128)), dim3(128), 0, 0, make_pose(pose1), make_pose(pose2), K,
+                       d_k1.p, n_keys1, d_t1.p, d_k2.p, n_keys2, d_t2.p, n_tp, d_xyz.p, d_upd.p, d_count.p);
+    VS_TRY(launch_ok("triangulate_kernel"));
+    VS_HIP(hipMemcpy(xyz, d_xyz.p, (size_t)n_tp * 3 * sizeof(float), hipMemcpyDefault));
+    if (updated) VS_HIP(hipMemcpy(updated, d_upd.p, (size_t)n_tp, hipMemcpyDefault));
+    int count = 0;
+    VS_HIP(hipMemcpy(&count, d_count.p, sizeof(int), hipMemcpyDefault));
+    if (n_updated) *n_updated = count;
     return VS_OK;
 }
 

@@ -243,3 +243,44 @@ def make_stereo_frame(n_left=400, n_right=420, seed=0, baseline_fx=0.12 * 170.5)
     K4 = np.array([170.5, 170.5, 191.5, 103.4], np.float32)
     return (np.ascontiguousarray(d0.astype(np.float32)), xy0, np.ascontiguousarray(d1[perm].astype(np.float32)),
             np.ascontiguousarray(xy1[perm]), K4, np.float32(baseline_fx), pose)
+
+
+def make_two_view_tracks(n_tp=500, seed=0, baseline=1.5, pixel_noise=0.5):
+    """Two frames as Tracking::updateTrackedPoints sees them (src/core/tracking.cc:378-451): float
+    poses of the oldest and newest frame of the window, their integer keypoints, the per-point
+    track tables (keypoint index or -1) and the current world points.  Most points have usable
+    parallax; some are far away (parallax cosine above 0.9998), some lie behind a camera or
+    closer than the 0.2 depth gate after triangulation, some are untracked in one frame."""
+    rng = np.random.default_rng(0xD17 + seed)
+    K4 = np.array([170.5, 170.5, 191.5, 103.4], np.float32)
+    q1 = _quat_from_rpy(rng.normal(0, 0.03, 3)); t1 = rng.normal(0, 0.3, 3)
+    q2 = _quat_from_rpy(rng.normal(0, 0.08, 3)); t2 = t1 + np.array([baseline, 0.2, 0.1]) + rng.normal(0, 0.05, 3)
+    R1, R2 = _quat_R(q1), _quat_R(q2)
+    depth = rng.uniform(1.0, 15.0, n_tp)
+    far = rng.random(n_tp) < 0.1
+    depth[far] = rng.uniform(300.0, 3000.0, far.sum())            # negligible parallax
+    u = rng.uniform(20, 2 * K4[2] - 20, n_tp)
+    v = rng.uniform(10, 2 * K4[3] - 10, n_tp)
+    Pc1 = np.stack([(u - K4[2]) / K4[0] * depth, depth, -(v - K4[3]) / K4[1] * depth], axis=1)
+    Pw = (Pc1 - t1) @ R1
+    Pc2 = Pw @ R2.T + t2
+
+    def pix(Pc):
+        x = K4[0] * Pc[:, 0] / Pc[:, 1] + K4[2]
+        y = -K4[1] * Pc[:, 2] / Pc[:, 1] + K4[3]
+        return np.stack([x, y], axis=1)
+
+    k1 = np.round(pix(Pc1) + rng.normal(0, pixel_noise, (n_tp, 2))).astype(np.int32)
+    k2 = np.round(pix(Pc2) + rng.normal(0, pixel_noise, (n_tp, 2))).astype(np.int32)
+    wild = rng.random(n_tp) < 0.1                                # mismatches: rays that diverge or
+    k2[wild] += rng.integers(-150, 151, (int(wild.sum()), 2)).astype(np.int32)   # meet behind a camera
+    p1, p2 = rng.permutation(n_tp), rng.permutation(n_tp)
+    keys1 = np.empty_like(k1); keys1[p1] = k1
+    keys2 = np.empty_like(k2); keys2[p2] = k2
+    tracks1, tracks2 = p1.astype(np.int32), p2.astype(np.int32)
+    tracks1[rng.random(n_tp) < 0.1] = -1
+    tracks2[rng.random(n_tp) < 0.1] = -1
+    pose1 = np.concatenate([t1, q1]).astype(np.float32)
+    pose2 = np.concatenate([t2, q2]).astype(np.float32)
+    xyz0 = (Pw + rng.normal(0, 0.05, Pw.shape)).astype(np.float32)
+    return pose1, pose2, K4, keys1, tracks1, keys2, tracks2, np.ascontiguousarray(xyz0)

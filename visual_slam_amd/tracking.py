@@ -1,5 +1,5 @@
 """Python wrappers of the per-frame tracking helpers of the C ABI (reference:
-src/core/tracking.cc:70-78, 346-377, 453-496; src/core/frame.cc:45-86)."""
+src/core/tracking.cc:70-78, 346-377, 378-451, 453-496; src/core/frame.cc:45-86)."""
 import ctypes as C
 
 import numpy as np
@@ -78,3 +78,19 @@ def compute_points3d(desc0, xy0, desc1, xy1, K4, baseline_fx, pose):
                                   C.c_float(baseline_fx), ptr(pose, C.c_float), ptr(good, C.c_uint8),
                                   ptr(xyz, C.c_float), ptr(loc, C.c_int32)))
     return good, xyz, loc
+
+
+def triangulate_tracks(pose1, pose2, K4, key_xy1, tracks1, key_xy2, tracks2, xyz):
+    """Tracking::updateTrackedPoints.  Returns (xyz, updated, n_updated)."""
+    lib = _lib.load()
+    pose1, pose2, K4 = _f32(pose1), _f32(pose2), _f32(K4)
+    k1, k2 = _i32(key_xy1).reshape(-1, 2), _i32(key_xy2).reshape(-1, 2)
+    t1, t2 = _i32(tracks1), _i32(tracks2)
+    out = _f32(xyz).reshape(-1, 3).copy()
+    upd = np.zeros(len(out), np.uint8)
+    n = C.c_int32(0)
+    check(lib.vs_triangulate_tracks(ptr(pose1, C.c_float), ptr(pose2, C.c_float), ptr(K4, C.c_float),
+                                    ptr(k1, C.c_int32), len(k1), ptr(t1, C.c_int32),
+                                    ptr(k2, C.c_int32), len(k2), ptr(t2, C.c_int32), len(out),
+                                    ptr(out, C.c_float), ptr(upd, C.c_uint8), C.byref(n)))
+    return out, upd, n.value

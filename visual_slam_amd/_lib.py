@@ -65,10 +65,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("VSLAM_HIP_LIB", LIB_PATH)     # developer knob: an alternative build
+    if not os.path.exists(path):
         raise ImportError("libvslam_hip.so not found at %s: build it with `make` (hipcc, gfx950); "
-                          "there is no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                          "there is no CPU fallback" % path)
+    lib = C.CDLL(path)
     lib.vs_last_error_string.restype = C.c_char_p
     lib.vs_version.restype = C.c_char_p
     lib.vs_lm_default_options.restype = None

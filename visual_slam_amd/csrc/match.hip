@@ -262,10 +262,27 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < 2; n++)
+#ifndef VS_EXP_NO_MFMA      // ablation build (wrong results) when defined: everything but the MFMAs
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][kt * (kBK / 16) + ks], bf[n], acc[m][n], 0, 0, 0);
+#else
+                    acc[m][n][0] += (float)bf[n][0] + (float)af[m][kt * (kBK / 16) + ks][0];
+#endif
         }
     }
 
+#ifdef VS_EXP_NO_EPILOGUE   // ablation build (wrong results): times the K loop without the top-2 epilogue
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) sum += acc[m][n][r];
+        if (sum == 12345.678f) col_part[0] = make_float2(sum, sum);
+        continue;
+    }
+#endif
     // ---- epilogue --------------------------------------------------------------------------
     // element (m, n, r) of this lane: row gi = i0 + wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
     //                                 col gj = j0 + wc*64 + n*32 + (lane&31)

@@ -183,6 +183,7 @@ syrk_update_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int k0, int 
 // instructions; the order in which k is consumed is free as long as both operands agree, so lane
 // (l15, lk) takes k = 8 lk + s in step s and fetches its 8 values as four 16-byte LDS reads.
 constexpr int kFusedMaxRows = 448;   // widest trailing window (rows below the diagonal block)
+constexpr int kLookaheadMaxRows = kFusedMaxRows / 2;   // two panel buffers fit in LDS
 constexpr int kXS = 34;              // LDS row stride in doubles: 16-byte aligned rows, and the
                                      // 16 rows of one operand read start 4 banks apart
 constexpr int kWin = 512;            // circular LDS window of the right-hand side (>= 448 + 32)
@@ -207,6 +208,262 @@ __device__ __forceinline__ d4 frag_product(const real *a, const real *b)
     return e + o;
 }
 
+// 1 / d to double precision: hardware estimate + two Newton steps (d > 0, normal range).
+__device__ __forceinline__ real rcp_refined(real d)
+{
+    real y = __builtin_amdgcn_rcp(d);
+    y = fma(y, fma(-d, y, real(1)), y);
+    y = fma(y, fma(-d, y, real(1)), y);
+    return y;
+}
+
+// Value of `v` in lane `src` (uniform), as a scalar broadcast.
+__device__ __forceinline__ real lane_value(real v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Cholesky factor of the 32 x 32 diagonal block AND the inverse of that factor, by ONE wave with
+// everything in registers (no barriers, one LDS store per column): lane i < 32 holds row i of the
+// block (identity beyond nb), lane 32 + r holds row r of the identity.  A right-looking step c
+// reads the pivot from lane c, and every lane updates its row with the same instructions,
+//   w[j] -= (w[c] / d) * w_j[c]      (w_j[c] = column c at row j, read from lane j),
+// so the identity rows ride along exactly like panel rows below the block and finish as
+// I * L^-T: lane 32 + r ends up holding row r of L^-T = column r of L^-1.  The chain from one
+// pivot to the next contains the reciprocal of the pivot, one product and one fma; a step first
+// updates column c + 1 and starts the next pivot's reciprocal, then updates the other columns
+// while that chain is in flight.  The columns are scaled at the end (L[i][c] = w[c] / sqrt(d_c)),
+// with the 32 reciprocal square roots computed side by side in the lanes.  Straight-line code: a
+// non-positive pivot is replaced by 1 with selects, the first such column + 1 is returned (0 = none).
+// Outputs (LDS): Ld[c][i] = L[i][c] (entries above the diagonal are meaningless), Li = L^-1.
+__device__ __forceinline__ int potrf_inverse_wave(const real (*Wn)[kNB + 1], int lane,
+                                                  real (*Ld)[kNB + 1], real (*Li)[34])
+{
+    const int row = lane & 31;
+    const bool ident = lane >= 32;
+    real w[kNB];
+#pragma unroll
+    for (int j = 0; j < kNB; j++)
+        w[j] = ident ? (j == row ? real(1) : real(0)) : (j <= row ? Wn[row][j] : real(0));
+    int bad = 0;
+    real d = lane_value(w[0], 0);
+    bool neg = !(d > real(0));
+    bad = neg ? 1 : 0;
+    d = neg ? real(1) : d;
+    real rinv = rcp_refined(d);
+    real diag = real(1);                               // pivot of column `row` (block lanes)
+#pragma unroll
+    for (int c = 0; c < kNB; c++) {
+        w[c] = (neg && lane == c) ? real(1) : w[c];
+        diag = row == c ? d : diag;
+        const real u = w[c];
+        const real m = -(u * rinv);                    // minus the unit-diagonal factor entry of this row
+        if (c + 1 < kNB) {
+            w[c + 1] = fma(m, lane_value(u, c + 1), w[c + 1]);
+            d = lane_value(w[c + 1], c + 1);
+            neg = !(d > real(0));
+            bad = (neg && bad == 0) ? c + 2 : bad;
+            d = neg ? real(1) : d;
+            rinv = rcp_refined(d);
+        }
+#pragma unroll
+        for (int j = c + 2; j < kNB; j++) w[j] = fma(m, lane_value(u, j), w[j]);
+    }
+    // column scaling, all 32 reciprocal square roots at once (lane c and lane 32 + c hold pivot c)
+    const real rs = rsqrt_refined(diag);
+#pragma unroll
+    for (int c = 0; c < kNB; c++) {
+        real *dst = ident ? &Li[c][row] : &Ld[c][row];
+        *dst = w[c] * lane_value(rs, c);
+    }
+    return bad;
+}
+
+constexpr int kCholThreads = 512, kCholWaves = kCholThreads / 64;   // 8 waves: 256 VGPRs each
+
+// Whole factorisation in one workgroup of 8 waves, for windows of up to kLookaheadMaxRows rows (two
+// panel images fit in LDS).  Per 32-column panel k (diagonal block W_k, rem rows X_k below it,
+// both resident in LDS):
+//   A. wave 0 factors W_k and inverts the factor in registers (potrf_inverse_wave) while the other
+//      waves apply panel k-1's update to the part of the trailing window that panel k does not
+//      read (columns >= 32 of the window, global read-modify-write);
+//   B. X_k <- X_k * L_kk^-T on the matrix cores, to LDS and to global memory;
+//   C. panel k's update of the FIRST 32 columns of the window, LDS to LDS: rows 0..31 become
+//      W_k+1, the rows below become X_k+1 (the rows that newly enter the window come from global
+//      memory).  These columns never make a round trip through global memory.
+// The trailing window lives in L2; the block inverses are kept for the triangular solves.
+__global__ void __launch_bounds__(kCholThreads)
+chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restrict__ info,
+                   real *__restrict__ Linv, int buf_rows)
+{
+    __shared__ real Wn[kNB][kNB + 1];                            // diagonal block of the next panel
+    __shared__ real Ld[kNB][kNB + 1];                            // Ld[c][i] = L[i][c] of the current block
+    __shared__ __attribute__((aligned(16))) real Li[kNB][kXS];    // inverse of the block's factor
+    __shared__ int bad_s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    typedef real (*Panel)[kXS];
+    Panel Xcur = reinterpret_cast<Panel>(dyn_lds);
+    Panel Xoth = Xcur + buf_rows;                                 // second panel image
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
+    if (tid == 0) bad_s = 0;
+
+    // 16 x 16 tile (ti, tj) of the window update of the panel at `base` with rows `rem`, panel
+    // image X: global read-modify-write of  A[base + r][base + c] -= X[r] . X[c]
+    auto update_tile = [&](Panel X, int base, int rem, int ti, int tj) {
+        const int cc = 16 * tj + l15;
+        real old[4];
+        bool ok[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int r = 16 * ti + lk + 4 * v;
+            ok[v] = r < rem && cc <= r;
+            old[v] = ok[v] ? A[(int64_t)(base + r) * ld + base + cc] : real(0);
+        }
+        real a[8], b[8];
+        load_frag(&X[16 * ti + l15][0], lk, a);
+        load_frag(&X[16 * tj + l15][0], lk, b);
+        const d4 p = frag_product(a, b);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int r = 16 * ti + lk + 4 * v;
+            if (ok[v]) A[(int64_t)(base + r) * ld + base + cc] = old[v] - p[v];
+        }
+    };
+    // tiles (ti, tj) with ti >= tj >= t0 of a window of nrt tile rows, numbered t = 0, 1, ...
+    auto lower_tiles = [&](Panel X, int base, int rem, int t0, int first, int stride) {
+        const int nrt = (rem + 15) >> 4, m = nrt - t0;
+        const int n_tiles = m > 0 ? m * (m + 1) / 2 : 0;
+        for (int t = first; t < n_tiles; t += stride) {
+            int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (a * (a + 1) / 2 > t) a--;
+            while ((a + 1) * (a + 2) / 2 <= t) a++;
+            update_tile(X, base, rem, a + t0, t - a * (a + 1) / 2 + t0);
+        }
+    };
+    auto panel_rows = [&](int k0) { return max(0, min(n - (k0 + min(kNB, n - k0)), bw)); };
+
+    // panel 0: diagonal block and panel rows from global memory
+    {
+        const int nb = min(kNB, n), rem = panel_rows(0);
+        for (int e = tid; e < kNB * kNB; e += kCholThreads) {
+            const int bi = e / kNB, bj = e % kNB;
+            Wn[bi][bj] = (bi < nb && bj <= bi) ? A[(int64_t)bi * ld + bj] : (bi == bj ? real(1) : real(0));
+        }
+        for (int e = tid; e < ((rem + 15) & ~15) * kNB; e += kCholThreads) {
+            const int r = e / kNB, c = e % kNB;
+            const int i = nb + r;
+            Xcur[r][c] = (r < rem && c < nb && i - c <= bw) ? A[(int64_t)i * ld + c] : real(0);
+        }
+    }
+    __syncthreads();
+    int rem_prev = 0, base_prev = 0;
+    for (int k0 = 0; k0 < n; k0 += kNB) {
+        const int nb = min(kNB, n - k0);
+        const int base = k0 + nb;
+        const int rem = panel_rows(k0);
+        const int nrt = (rem + 15) >> 4;                          // 16-row tiles of the panel
+        real *Lp = Linv + (int64_t)(k0 / kNB) * kNB * kNB;
+#ifdef VS_CHOL_TIMING
+        unsigned long long st0 = __builtin_readcyclecounter();
+#endif
+        // A. factor + invert the diagonal block (wave 0) | rest of the previous panel's update
+        if (wave == 0) {
+            const int bad = potrf_inverse_wave(Wn, lane, Ld, Li);
+            if (lane == 0 && bad && bad_s == 0) bad_s = k0 + bad;
+        }
+        else if (k0 > 0) lower_tiles(Xoth, base_prev, rem_prev, 2, wave - 1, kCholWaves - 1);
+#ifdef VS_CHOL_TIMING
+        unsigned long long st1 = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+#ifdef VS_CHOL_TIMING
+        unsigned long long st2 = __builtin_readcyclecounter();
+#endif
+        // the block's factor and its inverse go to global memory; Wn is reset to the identity
+        for (int e = tid; e < kNB * kNB; e += kCholThreads) {
+            const int r = e / kNB, c = e % kNB;
+            if (r >= c && r < nb) A[(int64_t)(k0 + r) * ld + k0 + c] = Ld[c][r];
+            Lp[e] = Li[r][c];
+            Wn[r][c] = r == c ? real(1) : real(0);
+        }
+        if (rem <= 0) break;                                      // uniform: last panel
+        // B. X <- X * Li^T
+        {
+            real b0[8], b1[8];
+            load_frag(&Li[l15][0], lk, b0);
+            load_frag(&Li[16 + l15][0], lk, b1);
+            for (int ti = wave; ti < nrt; ti += kCholWaves) {
+                real a[8];
+                load_frag(&Xcur[16 * ti + l15][0], lk, a);
+                const d4 p0 = frag_product(a, b0), p1 = frag_product(a, b1);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * ti + lk + 4 * v;
+                    Xcur[r][l15] = p0[v];
+                    Xcur[r][16 + l15] = p1[v];
+                    const int i = base + r;
+                    if (r < rem) {
+                        if (l15 < nb && i - (k0 + l15) <= bw) A[(int64_t)i * ld + k0 + l15] = p0[v];
+                        if (16 + l15 < nb && i - (k0 + 16 + l15) <= bw) A[(int64_t)i * ld + k0 + 16 + l15] = p1[v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#ifdef VS_CHOL_TIMING
+        unsigned long long st3 = __builtin_readcyclecounter();
+#endif
+        const int k0n = base, nbn = min(kNB, n - k0n);            // next panel (nbn > 0 as rem > 0)
+        const int remn = panel_rows(k0n);
+        {
+            // C. first 32 columns of the window -> next diagonal block and next panel rows.
+            //    Tile list: (0,0), (1,0), (1,1), (2,0), (2,1), ...
+            const int n_first = nrt == 1 ? 1 : 2 * nrt - 1;
+#pragma unroll 1
+            for (int idx = wave; idx < n_first; idx += kCholWaves) {
+                const int ti = idx == 0 ? 0 : (idx + 1) >> 1, tj = idx == 0 ? 0 : (idx + 1) & 1;
+                const int cc = 16 * tj + l15;
+                real old[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * ti + lk + 4 * v;
+                    old[v] = (r < rem && cc <= r) ? A[(int64_t)(base + r) * ld + base + cc] : real(0);
+                }
+                real a[8], b[8];
+                load_frag(&Xcur[16 * ti + l15][0], lk, a);
+                load_frag(&Xcur[16 * tj + l15][0], lk, b);
+                const d4 p = frag_product(a, b);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * ti + lk + 4 * v;
+                    if (r >= rem) continue;
+                    if (r < kNB) { if (cc <= r) Wn[r][cc] = old[v] - p[v]; }
+                    else Xoth[r - kNB][cc] = cc < nbn ? old[v] - p[v] : real(0);
+                }
+            }
+            // rows that enter the window (not touched by this panel's update) and zero padding
+            const int r_lo = max(rem - kNB, 0), r_hi = (remn + 15) & ~15;
+            for (int e = r_lo * kNB + tid; e < r_hi * kNB; e += kCholThreads) {
+                const int r = e / kNB, c = e % kNB;
+                const int i = k0n + nbn + r;
+                Xoth[r][c] = (r < remn && c < nbn && i - (k0n + c) <= bw) ? A[(int64_t)i * ld + k0n + c] : real(0);
+            }
+        }
+        __syncthreads();
+#ifdef VS_CHOL_TIMING
+        if (tid == 0 && k0 == 32 * 3)
+            printf("panel rem %d: potrf wave %llu, phase A %llu, product %llu, next columns / window %llu\n", rem,
+                   st1 - st0, st2 - st0, st3 - st2, (unsigned long long)__builtin_readcyclecounter() - st3);
+#endif
+        rem_prev = rem; base_prev = base;
+        { Panel t = Xcur; Xcur = Xoth; Xoth = t; }
+    }
+    if (tid == 0 && bad_s && *info == 0) *info = bad_s;
+}
+
 // Column j of the 32 x 32 block has received its last update: its 32 owners (one half-wave, lane
 // bi = row) read the pivot from the diagonal owner's lane, scale the column by 1 / sqrt(pivot) and
 // publish the finished factor column (zero above the diagonal).  A non-positive pivot is
@@ -229,7 +486,8 @@ __device__ __forceinline__ real publish_column(real w, int j, int bi, int lane, 
     return l;
 }
 
-// Per 32-column panel:
+// Single-workgroup factorisation for windows too wide for two panel buffers (16 waves, no
+// look-ahead).  Per 32-column panel:
 //   1. the diagonal block goes to registers (one element per thread), the panel rows below it to
 //      LDS (zero outside the band and beyond the matrix);
 //   2. 32 column steps, one barrier each, factor the block and invert the factor: a step reads the
@@ -608,18 +866,25 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
 {
     const int window = bw < n ? bw : n;
     if (window <= kFusedMaxRows) {
-        const size_t lds = (size_t)((window + 15) & ~15) * kXS * sizeof(real);
         static bool lds_limit_raised = false;     // dynamic LDS beyond the default limit
         if (!lds_limit_raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kFusedMaxRows * kXS * (int)sizeof(real)) != hipSuccess) {
-                set_error("cannot raise the dynamic LDS limit of the fused Cholesky kernel");
+            const int max_lds = kFusedMaxRows * kXS * (int)sizeof(real);
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_window_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
+                set_error("cannot raise the dynamic LDS limit of the single-workgroup Cholesky kernels");
                 return VS_ERR_HIP;
             }
             lds_limit_raised = true;
         }
-        hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(1024), lds, s, A, n, ld, bw, info, Linv);
+        const int buf_rows = (window + 15) & ~15;
+        if (window <= kLookaheadMaxRows)
+            hipLaunchKernelGGL(chol_window_kernel, dim3(1), dim3(kCholThreads), (size_t)2 * buf_rows * kXS * sizeof(real), s,
+                               A, n, ld, bw, info, Linv, buf_rows);
+        else
+            hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(1024), (size_t)buf_rows * kXS * sizeof(real), s,
+                               A, n, ld, bw, info, Linv);
         hipLaunchKernelGGL(chol_trsv_window_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
     } else {
         for (int k0 = 0; k0 < n; k0 += kNB) {

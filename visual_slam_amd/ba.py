@@ -147,8 +147,14 @@ class BAProblem:
         self._cb = _lib.ALLREDUCE_FN(tramp)
         check(self.lib.vs_ba_set_allreduce(self.h, self._cb, None))
 
-    def lm_step(self, radius=1e4):
-        dcam = np.zeros((self.Nc, 6)); dpt = np.zeros((self.Np, 3)); mcc = C.c_double(0)
+    def lm_step(self, radius=1e4, fetch=True):
+        """One LM step.  fetch=False leaves the step on the device (as inside vs_ba_solve) and
+        returns only the model cost change."""
+        mcc = C.c_double(0)
+        if not fetch:
+            check(self.lib.vs_ba_lm_step(self.h, C.c_double(radius), None, None, C.byref(mcc)))
+            return None, None, mcc.value
+        dcam = np.zeros((self.Nc, 6)); dpt = np.zeros((self.Np, 3))
         check(self.lib.vs_ba_lm_step(self.h, C.c_double(radius), ptr(dcam, C.c_double),
                                      ptr(dpt, C.c_double), C.byref(mcc)))
         return dcam, dpt, mcc.value

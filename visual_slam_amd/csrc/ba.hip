@@ -481,8 +481,6 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
                        h->pts.p, h->cam_used.p, h->pt_used.p, (int)(h->rank == 0), h->dcam.p, h->dpt.p,
                        h->t2.p, h->rpy2.p, h->pts2.p, h->cand_partial.p);
     VS_TRY(launch_check("candidate_kernel"));
-    // |x|^2 and |d|^2: strided sums of the interleaved partials
-    std::vector<real> hp;
     if (want_candidate_cost) {
         VS_TRY(prep_cameras(h, h->t2.p, h->rpy2.p));
         if (h->stage_cams)
@@ -494,13 +492,10 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         VS_TRY(launch_check("cost_kernel"));
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->cost_partial.p, h->scalars.p + 3);
     }
-    hp.resize((size_t)ncb * 2);
-    VS_HIP(hipMemcpyAsync(hp.data(), h->cand_partial.p, hp.size() * sizeof(real), hipMemcpyDeviceToHost, s));
-    VS_HIP(hipStreamSynchronize(s));
-    real xn = 0, dn = 0;
-    for (int i = 0; i < ncb; i++) { xn += hp[2 * (size_t)i]; dn += hp[2 * (size_t)i + 1]; }
-    real host4[4] = { 0, xn, dn, 0 };
-    VS_HIP(hipMemcpyAsync(h->scalars.p + 1, host4 + 1, 2 * sizeof(real), hipMemcpyHostToDevice, s));
+    // |x|^2 and |d|^2: sums of the interleaved per-block partials, on the device
+    hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(256), 0, s, ncb, h->cand_partial.p, h->scalars.p + 1);
+    VS_TRY(launch_check("sum_pairs_kernel"));
+    real host4[4] = { 0, 0, 0, 0 };
     VS_TRY(cross_gpu_sum(h, h->scalars.p, 4));
     VS_HIP(hipMemcpyAsync(host4, h->scalars.p, 4 * sizeof(real), hipMemcpyDeviceToHost, s));
     int info = 0;

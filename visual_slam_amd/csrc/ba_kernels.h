@@ -698,6 +698,18 @@ sum_partials_kernel(int n, const real *__restrict__ in, real *__restrict__ out)
     if (threadIdx.x == 0) *out = s;
 }
 
+// Sums of `n` interleaved pairs (a_i, b_i) -> out[0], out[1] (single block, fixed order).
+__global__ void __launch_bounds__(256)
+sum_pairs_kernel(int n, const real *__restrict__ in, real *__restrict__ out)
+{
+    __shared__ real red[4];
+    real a = real(0), b = real(0);
+    for (int i = threadIdx.x; i < n; i += 256) { a += in[2 * (int64_t)i]; b += in[2 * (int64_t)i + 1]; }
+    a = block_sum_256(a, red);
+    b = block_sum_256(b, red);
+    if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
 // LM diagonal for the cameras: lam = clamp(s^2 Udd, min_d, max_d) / (radius s^2), or an explicit
 // lam array; written to lam_out and added to the diagonal of S_cc in place.
 __global__ void camera_damping_kernel(int Nc, const real *__restrict__ udiag,

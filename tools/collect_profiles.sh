@@ -21,6 +21,7 @@ run_trace c4 python3 tools/prof_ba.py c4 20 &&
 run_trace c5shard python3 tools/prof_ba.py c5shard 20 &&
 run_trace match python3 tools/prof_match.py 64 3 &&
 run_trace lm_c2 python3 tools/time_lm.py c2 &&
+run_trace lm_c4 python3 tools/time_lm.py c4 &&
 run_trace lm_c5shard python3 tools/time_lm.py c5shard &&
 run_pmc c2_fetch FETCH_SIZE python3 tools/prof_ba.py c2 5 &&
 run_pmc c2_write WRITE_SIZE python3 tools/prof_ba.py c2 5 &&

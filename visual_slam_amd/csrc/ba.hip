@@ -341,16 +341,18 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
 {
     auto mark = [&](int i) { if (h->prof_ev) (void)hipEventRecord(h->prof_ev[i], h->stream); };
     mark(0);
-    VS_TRY(prep_cameras(h, t, rpy));
+    // few cameras: the landmark kernel builds the camera records itself (no separate pass)
+    if (!h->stage_cams) VS_TRY(prep_cameras(h, t, rpy));
     mark(1);
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
         hipLaunchKernelGGL(landmark_kernel<true>, dim3(h->n_lm4_blocks), dim3(kLmThreads), lds, h->stream,
-                           h->Np, h->Nc, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
-                           h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+                           h->Np, h->Nc, h->K, (const CamData *)nullptr, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p,
+                           h->hub, pd, h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
     else
         hipLaunchKernelGGL(landmark_kernel<false>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,
-                           h->Np, h->Nc, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
+                           h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
+                           (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
                            h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
     VS_TRY(launch_check("landmark_kernel"));
     mark(2);

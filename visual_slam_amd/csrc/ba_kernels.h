@@ -146,11 +146,10 @@ __device__ __forceinline__ void load_cam(const CamData *cams, int c, CamData &ou
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void prep_cameras_kernel(int Nc, const real *__restrict__ t,
-                                    const real *__restrict__ rpy, CamData *__restrict__ cams)
+// Camera record of camera c from its parameters: R = Rz(yaw) Ry(pitch) Rx(roll)
+// (reference: src/core/reprojection_error.h:32-35).
+__device__ __forceinline__ CamData make_cam(const real *__restrict__ t, const real *__restrict__ rpy, int c)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Nc) return;
     real sr, cr, sp, cp, sy, cy;
     sincos(rpy[3 * c], &sr, &cr);
     sincos(rpy[3 * c + 1], &sp, &cp);
@@ -161,7 +160,14 @@ __global__ void prep_cameras_kernel(int Nc, const real *__restrict__ t,
     d.R[6] = -sp;     d.R[7] = cp * sr;                d.R[8] = cp * cr;
     d.t[0] = t[3 * c]; d.t[1] = t[3 * c + 1]; d.t[2] = t[3 * c + 2];
     d.sy = sy; d.cy = cy; d.pad[0] = d.pad[1] = real(0);
-    cams[c] = d;
+    return d;
+}
+
+__global__ void prep_cameras_kernel(int Nc, const real *__restrict__ t,
+                                    const real *__restrict__ rpy, CamData *__restrict__ cams)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < Nc) cams[c] = make_cam(t, rpy, c);
 }
 
 // Block-wide sum of one value per thread (256 threads), result valid in thread 0.
@@ -202,10 +208,14 @@ constexpr int kLmPerBlock = kLmThreads / kLpl;        // landmarks per workgroup
 
 // (a)+(b), landmark side.  Four lanes per landmark j share its observations:
 // V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
-// Cameras come from LDS when they fit (STAGE_CAMS).
+// Cameras come from LDS when they fit (STAGE_CAMS).  With prep_t / prep_rpy given (STAGE_CAMS only)
+// every workgroup builds the camera records itself, straight into LDS, and workgroup 0 also
+// stores them to `cams_out` for the kernels that follow: no separate camera pass.
 template <bool STAGE_CAMS>
 __global__ void __launch_bounds__(kLmThreads)
 landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
+                const real *__restrict__ prep_t, const real *__restrict__ prep_rpy,
+                CamData *__restrict__ cams_out,
                 const real *__restrict__ pts, const int *__restrict__ pt_ptr,
                 const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
                 PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
@@ -215,9 +225,17 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
     CamData *scams = reinterpret_cast<CamData *>(smem_raw);
     __shared__ real red[4];
     if (STAGE_CAMS) {
-        const double2 *src = reinterpret_cast<const double2 *>(cams);
-        double2 *dst = reinterpret_cast<double2 *>(scams);
-        for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
+        if (prep_t) {
+            for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
+                const CamData d = make_cam(prep_t, prep_rpy, c);
+                scams[c] = d;
+                if (blockIdx.x == 0) cams_out[c] = d;
+            }
+        } else {
+            const double2 *src = reinterpret_cast<const double2 *>(cams);
+            double2 *dst = reinterpret_cast<double2 *>(scams);
+            for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
+        }
         __syncthreads();
     }
     const int j = blockIdx.x * kLmPerBlock + ((int)threadIdx.x >> 2);

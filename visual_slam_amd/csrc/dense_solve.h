@@ -208,15 +208,6 @@ __device__ __forceinline__ d4 frag_product(const real *a, const real *b)
     return e + o;
 }
 
-// 1 / d to double precision: hardware estimate + two Newton steps (d > 0, normal range).
-__device__ __forceinline__ real rcp_refined(real d)
-{
-    real y = __builtin_amdgcn_rcp(d);
-    y = fma(y, fma(-d, y, real(1)), y);
-    y = fma(y, fma(-d, y, real(1)), y);
-    return y;
-}
-
 // Value of `v` in lane `src` (uniform), as a scalar broadcast.
 __device__ __forceinline__ real lane_value(real v, int src)
 {
@@ -225,51 +216,122 @@ __device__ __forceinline__ real lane_value(real v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// 1 / d to double precision: hardware estimate (2^-24) + one cubically convergent step.
+__device__ __forceinline__ real rcp_cubic(real d)
+{
+    const real y = __builtin_amdgcn_rcp(d);
+    const real e = fma(-d, y, real(1));
+    return fma(y, fma(e, e, e), y);                     // y (1 + e + e^2)
+}
+
+constexpr int kHalf = kNB / 2;
+constexpr int kSS = kHalf + 2;                          // row stride of the half-block images in LDS
+
 // Cholesky factor of the 32 x 32 diagonal block AND the inverse of that factor, by ONE wave with
-// everything in registers (no barriers, one LDS store per column): lane i < 32 holds row i of the
-// block (identity beyond nb), lane 32 + r holds row r of the identity.  A right-looking step c
-// reads the pivot from lane c, and every lane updates its row with the same instructions,
+// the block in registers (no barriers): lane i < 32 holds row i of the block (identity beyond nb),
+// lane 32 + r holds row r of the identity.  A right-looking step c reads the pivot from lane c, and
+// every lane updates its row with the same instructions,
 //   w[j] -= (w[c] / d) * w_j[c]      (w_j[c] = column c at row j, read from lane j),
 // so the identity rows ride along exactly like panel rows below the block and finish as
-// I * L^-T: lane 32 + r ends up holding row r of L^-T = column r of L^-1.  The chain from one
-// pivot to the next contains the reciprocal of the pivot, one product and one fma; a step first
-// updates column c + 1 and starts the next pivot's reciprocal, then updates the other columns
-// while that chain is in flight.  The columns are scaled at the end (L[i][c] = w[c] / sqrt(d_c)),
-// with the 32 reciprocal square roots computed side by side in the lanes.  Straight-line code: a
-// non-positive pivot is replaced by 1 with selects, the first such column + 1 is returned (0 = none).
+// I * L^-T: lane 32 + r ends up holding row r of L^-T = column r of L^-1.
+// The chain from one pivot to the next is a lane read, the reciprocal of the pivot, one product
+// and one fma (a dependent fp64 operation costs ~44 cycles); a step first updates column c + 1 and
+// starts the next pivot's reciprocal, then updates the other columns while that chain is in flight.
+// The block is processed as two halves of 16 columns: the steps of a half only update the columns
+// of that half, and the update of columns 16..31 by the first 16 steps (the bulk of the lane-read
+// traffic in an unblocked sweep) is ONE 32 x 16 x 16 product on the fp64 matrix cores, staged
+// through wave-private LDS images.  Columns are scaled at the end (L[i][c] = w[c] / sqrt(d_c)),
+// with the 32 reciprocal square roots computed side by side in the lanes.  A non-positive pivot is
+// replaced by 1 with selects; the first such column + 1 is returned (0 = none).
 // Outputs (LDS): Ld[c][i] = L[i][c] (entries above the diagonal are meaningless), Li = L^-1.
-__device__ __forceinline__ int potrf_inverse_wave(const real (*Wn)[kNB + 1], int lane,
+// img: wave-private LDS scratch of 48 * kSS reals, 16-byte aligned.
+__device__ __forceinline__ int potrf_inverse_wave(const real (*Wn)[kNB + 1], int lane, real *img,
                                                   real (*Ld)[kNB + 1], real (*Li)[34])
 {
     const int row = lane & 31;
     const bool ident = lane >= 32;
-    real w[kNB];
+    real w[kNB], mm[kHalf];
 #pragma unroll
     for (int j = 0; j < kNB; j++)
         w[j] = ident ? (j == row ? real(1) : real(0)) : (j <= row ? Wn[row][j] : real(0));
     int bad = 0;
-    real d = lane_value(w[0], 0);
-    bool neg = !(d > real(0));
-    bad = neg ? 1 : 0;
-    d = neg ? real(1) : d;
-    real rinv = rcp_refined(d);
     real diag = real(1);                               // pivot of column `row` (block lanes)
 #pragma unroll
-    for (int c = 0; c < kNB; c++) {
-        w[c] = (neg && lane == c) ? real(1) : w[c];
-        diag = row == c ? d : diag;
-        const real u = w[c];
-        const real m = -(u * rinv);                    // minus the unit-diagonal factor entry of this row
-        if (c + 1 < kNB) {
-            w[c + 1] = fma(m, lane_value(u, c + 1), w[c + 1]);
-            d = lane_value(w[c + 1], c + 1);
-            neg = !(d > real(0));
-            bad = (neg && bad == 0) ? c + 2 : bad;
-            d = neg ? real(1) : d;
-            rinv = rcp_refined(d);
-        }
+    for (int h = 0; h < 2; h++) {
+        const int c0 = h * kHalf, c1 = c0 + kHalf;
+        real d = lane_value(w[c0], c0);
+        bool neg = !(d > real(0));
+        bad = (neg && bad == 0) ? c0 + 1 : bad;
+        d = neg ? real(1) : d;
+        real rinv = rcp_cubic(d);
 #pragma unroll
-        for (int j = c + 2; j < kNB; j++) w[j] = fma(m, lane_value(u, j), w[j]);
+        for (int c = c0; c < c1; c++) {
+            w[c] = (neg && lane == c) ? real(1) : w[c];
+            diag = row == c ? d : diag;
+            const real u = w[c];
+            const real m = -(u * rinv);                // minus the unit-diagonal factor entry of this row
+            if (h == 0) mm[c - c0] = m;
+            if (c + 1 < c1) {
+                w[c + 1] = fma(m, lane_value(u, c + 1), w[c + 1]);
+                d = lane_value(w[c + 1], c + 1);
+                neg = !(d > real(0));
+                bad = (neg && bad == 0) ? c + 2 : bad;
+                d = neg ? real(1) : d;
+                rinv = rcp_cubic(d);
+            }
+#pragma unroll
+            for (int j = c + 2; j < c1; j++) w[j] = fma(m, lane_value(u, j), w[j]);
+        }
+        if (h == 0) {
+            // columns 16..31 += M U^T for block rows 16..31 (lanes 16..31) and identity rows 0..15
+            // (lanes 32..47); the other lanes' columns 16..31 are not needed or do not change.
+            // Images: M rows of lanes 16..47 at img[(lane - 16) * kSS], U = block rows 16..31,
+            // columns 0..15 (unscaled), at img[(32 + lane - 16) * kSS].
+            real *Mimg = img, *Uimg = img + 32 * kSS;
+            if (lane >= 16 && lane < 48) {
+                double2 *dst = reinterpret_cast<double2 *>(Mimg + (lane - 16) * kSS);
+#pragma unroll
+                for (int q = 0; q < kHalf / 2; q++) dst[q] = make_double2(mm[2 * q], mm[2 * q + 1]);
+            }
+            if (lane >= 16 && lane < 32) {
+                double2 *dst = reinterpret_cast<double2 *>(Uimg + (lane - 16) * kSS);
+#pragma unroll
+                for (int q = 0; q < kHalf / 2; q++) dst[q] = make_double2(w[2 * q], w[2 * q + 1]);
+            }
+            const int l15 = lane & 15, lk = lane >> 4;
+            real bfr[4], af[2][4];
+            {
+                const double2 *p = reinterpret_cast<const double2 *>(Uimg + l15 * kSS + 4 * lk);
+                const double2 v0 = p[0], v1 = p[1];
+                bfr[0] = v0.x; bfr[1] = v0.y; bfr[2] = v1.x; bfr[3] = v1.y;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const double2 *p = reinterpret_cast<const double2 *>(Mimg + (16 * t + l15) * kSS + 4 * lk);
+                const double2 v0 = p[0], v1 = p[1];
+                af[t][0] = v0.x; af[t][1] = v0.y; af[t][2] = v1.x; af[t][3] = v1.y;
+            }
+            d4 acc[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#pragma unroll
+            for (int sft = 0; sft < 4; sft++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t][sft], bfr[sft], acc[t], 0, 0, 0);
+            // D[row lk + 4 v][col l15] of tile t -> image rows 16 t + lk + 4 v (the M image is dead)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) Mimg[(16 * t + lk + 4 * v) * kSS + l15] = acc[t][v];
+            if (lane >= 16 && lane < 48) {
+                const double2 *src = reinterpret_cast<const double2 *>(Mimg + (lane - 16) * kSS);
+#pragma unroll
+                for (int q = 0; q < kHalf / 2; q++) {
+                    const double2 v = src[q];
+                    w[kHalf + 2 * q] += v.x;
+                    w[kHalf + 2 * q + 1] += v.y;
+                }
+            }
+        }
     }
     // column scaling, all 32 reciprocal square roots at once (lane c and lane 32 + c hold pivot c)
     const real rs = rsqrt_refined(diag);
@@ -300,6 +362,7 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
 {
     __shared__ real Wn[kNB][kNB + 1];                            // diagonal block of the next panel
     __shared__ real Ld[kNB][kNB + 1];                            // Ld[c][i] = L[i][c] of the current block
+    __shared__ __attribute__((aligned(16))) real wimg[48 * kSS];  // scratch of the factoring wave
     __shared__ __attribute__((aligned(16))) real Li[kNB][kXS];    // inverse of the block's factor
     __shared__ int bad_s;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -310,37 +373,60 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
     if (tid == 0) bad_s = 0;
 
-    // 16 x 16 tile (ti, tj) of the window update of the panel at `base` with rows `rem`, panel
-    // image X: global read-modify-write of  A[base + r][base + c] -= X[r] . X[c]
-    auto update_tile = [&](Panel X, int base, int rem, int ti, int tj) {
-        const int cc = 16 * tj + l15;
-        real old[4];
-        bool ok[4];
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int r = 16 * ti + lk + 4 * v;
-            ok[v] = r < rem && cc <= r;
-            old[v] = ok[v] ? A[(int64_t)(base + r) * ld + base + cc] : real(0);
-        }
-        real a[8], b[8];
-        load_frag(&X[16 * ti + l15][0], lk, a);
-        load_frag(&X[16 * tj + l15][0], lk, b);
-        const d4 p = frag_product(a, b);
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int r = 16 * ti + lk + 4 * v;
-            if (ok[v]) A[(int64_t)(base + r) * ld + base + cc] = old[v] - p[v];
-        }
-    };
-    // tiles (ti, tj) with ti >= tj >= t0 of a window of nrt tile rows, numbered t = 0, 1, ...
+    // tiles (ti, tj) with ti >= tj >= t0 of a window of nrt tile rows, numbered t = 0, 1, ...; a
+    // wave takes tiles first, first + stride, ... two at a time, and fetches the old values of its
+    // next two tiles before it works on the current two (the read-modify-write of the window is
+    // bound by the latency of those loads, not by the products)
     auto lower_tiles = [&](Panel X, int base, int rem, int t0, int first, int stride) {
         const int nrt = (rem + 15) >> 4, m = nrt - t0;
         const int n_tiles = m > 0 ? m * (m + 1) / 2 : 0;
-        for (int t = first; t < n_tiles; t += stride) {
-            int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-            while (a * (a + 1) / 2 > t) a--;
-            while ((a + 1) * (a + 2) / 2 <= t) a++;
-            update_tile(X, base, rem, a + t0, t - a * (a + 1) / 2 + t0);
+        struct Pair { int ti[2], tj[2]; real old[2][4]; bool ok[2][4]; };
+        auto fetch = [&](int t, Pair &pr) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int tq = t + q * stride;
+                int a = (int)((sqrtf(8.0f * (float)tq + 1.0f) - 1.0f) * 0.5f);
+                while (a * (a + 1) / 2 > tq) a--;
+                while ((a + 1) * (a + 2) / 2 <= tq) a++;
+                const bool on = tq < n_tiles;
+                pr.ti[q] = on ? a + t0 : 0;
+                pr.tj[q] = on ? tq - a * (a + 1) / 2 + t0 : 0;
+                const int cc = 16 * pr.tj[q] + l15;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * pr.ti[q] + lk + 4 * v;
+                    pr.ok[q][v] = on && r < rem && cc <= r;
+                    pr.old[q][v] = pr.ok[q][v] ? A[(int64_t)(base + r) * ld + base + cc] : real(0);
+                }
+            }
+        };
+        Pair cur, nxt;
+        if (first < n_tiles) fetch(first, cur);
+        for (int t = first; t < n_tiles; t += 2 * stride) {
+            const int tn = t + 2 * stride;
+            if (tn < n_tiles) fetch(tn, nxt);
+            real a[2][8], b[2][8];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                load_frag(&X[16 * cur.ti[q] + l15][0], lk, a[q]);
+                load_frag(&X[16 * cur.tj[q] + l15][0], lk, b[q]);
+            }
+            d4 p[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#pragma unroll
+            for (int sft = 0; sft < 8; sft++)
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    p[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][sft], b[q][sft], p[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int cc = 16 * cur.tj[q] + l15;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int r = 16 * cur.ti[q] + lk + 4 * v;
+                    if (cur.ok[q][v]) A[(int64_t)(base + r) * ld + base + cc] = cur.old[q][v] - p[q][v];
+                }
+            }
+            cur = nxt;
         }
     };
     auto panel_rows = [&](int k0) { return max(0, min(n - (k0 + min(kNB, n - k0)), bw)); };
@@ -371,7 +457,7 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
 #endif
         // A. factor + invert the diagonal block (wave 0) | rest of the previous panel's update
         if (wave == 0) {
-            const int bad = potrf_inverse_wave(Wn, lane, Ld, Li);
+            const int bad = potrf_inverse_wave(Wn, lane, wimg, Ld, Li);
             if (lane == 0 && bad && bad_s == 0) bad_s = k0 + bad;
         }
         else if (k0 > 0) lower_tiles(Xoth, base_prev, rem_prev, 2, wave - 1, kCholWaves - 1);
@@ -390,6 +476,18 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
             Wn[r][c] = r == c ? real(1) : real(0);
         }
         if (rem <= 0) break;                                      // uniform: last panel
+        // Band storage: the rows that enter the window two panels from now are first touched here,
+        // one cache line per thread, so that their first real use does not wait for HBM.  The value
+        // is only consumed (by an empty asm) at the end of the panel.
+        real warm = real(0);
+        if (bw < n) {
+            const int lines_per_row = ((bw + 1) * (int)sizeof(real) + 127) / 128 + 1;
+            const int i = base + rem + kNB + tid / lines_per_row;
+            if (tid < kNB * lines_per_row && i < n) {
+                const real *q = A + (int64_t)i * ld + (i - bw) + (tid % lines_per_row) * 16;
+                if (q <= A + (int64_t)i * ld + i) warm = *reinterpret_cast<const volatile real *>(q);
+            }
+        }
         // B. X <- X * Li^T
         {
             real b0[8], b1[8];
@@ -452,6 +550,7 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
                 Xoth[r][c] = (r < remn && c < nbn && i - (k0n + c) <= bw) ? A[(int64_t)i * ld + k0n + c] : real(0);
             }
         }
+        asm volatile("" :: "v"(warm));
         __syncthreads();
 #ifdef VS_CHOL_TIMING
         if (tid == 0 && k0 == 32 * 3)

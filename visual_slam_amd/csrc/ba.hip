@@ -453,8 +453,8 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         VS_CHECK(elems * sizeof(real) <= (size_t)16 << 30, VS_ERR_UNSUPPORTED,
                  "reduced system of %d cameras with camera-pair gap %d exceeds this build's solver limit (16 GiB)",
                  Nc, h->max_pair_gap);
-        if (h->dense.n < elems) VS_TRY(h->dense.alloc(elems));
-        VS_HIP(hipMemsetAsync(h->dense.p, 0, elems * sizeof(real), s));
+        if (h->dense.n < elems + kNB) VS_TRY(h->dense.alloc(elems + kNB));   // padded: see cholesky_solve
+        VS_HIP(hipMemsetAsync(h->dense.p, 0, (elems + kNB) * sizeof(real), s));
         real *A = h->dense.p + (banded ? band : 0);
         const int64_t ne = (int64_t)Nc * 36 + (int64_t)h->nb_off * 36;
         hipLaunchKernelGGL(assemble_lower_kernel, dim3(div_up(ne, 256)), dim3(256), 0, s, Nc, h->nb_off,

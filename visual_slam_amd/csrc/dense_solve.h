@@ -733,6 +733,14 @@ chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restri
     if (tid == 0 && bad_s && *info == 0) *info = bad_s;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every
+// outstanding global load and store of the wave, which puts the latency of loads fetched ahead of
+// their use (and of fire-and-forget stores) on the critical path of each barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Sum over the 16 lanes of a DPP row, result in every lane of the row.
 template <int CTRL>
 __device__ __forceinline__ real dpp_move(real v)
@@ -758,56 +766,125 @@ __device__ __forceinline__ real sum32(real v)
 // of a row add up.  The active part of the right-hand side lives in a circular LDS window; block
 // inverses and factor rows, which do not depend on the right-hand side, are fetched before the
 // dependent work of a panel starts.
+// Sum over groups of 8 consecutive lanes (result in every lane of the group): three DPP steps.
+__device__ __forceinline__ real sum8(real v)
+{
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    return v;
+}
+
+template <int QN>   // ceil(window / 128): turns of the forward update (128 rows per turn)
 __global__ void __launch_bounds__(1024)
 chol_trsv_window_kernel(const real *__restrict__ A, int n, int64_t ld, int bw,
                         const real *__restrict__ Linv, real *__restrict__ b)
 {
     __shared__ real win[kWin];
-    __shared__ real ys[kNB];
+    __shared__ __attribute__((aligned(16))) real ys[kNB];
     const int tid = threadIdx.x;
-    const int r32 = tid / kNB, m = tid % kNB;
-    const int wave = tid >> 6, half = (tid >> 5) & 1;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int g = lane & 7, sub = lane >> 3;                       // forward pass: 8 lanes x 4 columns per row
     const int reach = kNB + min(bw, n);                            // rows a panel touches
-    constexpr int kMaxQ = kFusedMaxRows / 32;
-    // ---- forward: L y = b
+    // ---- forward: L y = b.  A row of 32 factor or block-inverse entries is shared by 8 lanes, each
+    // multiplying 4 consecutive columns in registers, so a row sum is three DPP steps.
     for (int i = tid; i < min(n, reach); i += 1024) win[i & (kWin - 1)] = b[i];
-    real li = Linv[r32 * kNB + m];
-    __syncthreads();
-    for (int k0 = 0; k0 < n; k0 += kNB) {
+    // block inverse: waves 0..3, row 8 * wave + sub, columns 4 g .. 4 g + 3
+    auto fetch_inverse = [&](int p0, real *out) {
+        const int pc = min(p0, ((n - 1) / kNB) * kNB);
+        const real *src = Linv + (int64_t)(pc / kNB) * kNB * kNB + (8 * (wave & 3) + sub) * kNB + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = src[e];
+    };
+    // Factor rows below the diagonal block of the panel at p0: turn q covers rows
+    // 128 q + 8 wave + sub.  Loads are unconditional (addresses clamped into the factor) and their
+    // values are masked only where they are used, one panel later: a fixed number of loads in
+    // flight lets the waits for older loads leave the younger ones outstanding, and nothing at the
+    // point of the fetch depends on the data.
+    auto fetch_rows = [&](int p0, real (*out)[4]) {
+        const int pc = min(p0, ((n - 1) / kNB) * kNB);             // clamp past-the-end panels
+        const int nbp = min(kNB, n - pc), basep = pc + nbp;
+        const int remp = p0 < n ? max(0, min(n - basep, bw)) : 0;
+#pragma unroll
+        for (int q = 0; q < QN; q++) {
+            const int r = 128 * q + 8 * wave + sub;
+            // columns are not clamped: the caller pads the factor storage by kNB elements
+            const real *src = A + (int64_t)(remp > 0 ? basep + min(r, remp - 1) : basep - 1) * ld + pc + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[q][e] = src[e];          // raw: masked where it is used
+        }
+    };
+    // Two register sets take turns (the loop is unrolled by two panels), so a value fetched in one
+    // panel is consumed in the next without a register copy at the loop edge, which would wait for it.
+    auto forward_panel = [&](int k0, const real *li, const real (*raw)[4], real *li_n, real (*raw_n)[4]) {
         const int nb = min(kNB, n - k0);
         const int base = k0 + nb;
         const int rem = max(0, min(n - base, bw));
-        // factor rows of this panel (2 rows per wave and turn, lanes along the 32 columns)
-        real av[kMaxQ];
+#ifdef VS_CHOL_TIMING
+        unsigned long long tt0 = __builtin_readcyclecounter();
+#endif
+        // this panel's block inverse and factor rows were fetched one panel ahead (li, raw); fetch
+        // the next panel's into the other register set now
+        real av[QN][4];
 #pragma unroll
-        for (int q = 0; q < kMaxQ; q++) {
-            const int r = 2 * (wave + 16 * q) + half, i = base + r;
-            av[q] = (r < rem && m < nb && i - (k0 + m) <= bw) ? A[(int64_t)i * ld + k0 + m] : real(0);
-        }
-        const real bp = k0 + m < n ? win[(k0 + m) & (kWin - 1)] : real(0);
-        const real yv = sum32(li * bp);                            // (Linv b_panel)[r32]
-        if (m == 0) { ys[r32] = yv; if (r32 < nb) b[k0 + r32] = yv; }
-        if (k0 + kNB < n) li = Linv[(int64_t)(k0 / kNB + 1) * kNB * kNB + r32 * kNB + m];
+        for (int q = 0; q < QN; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int r = 128 * q + 8 * wave + sub, c = 4 * g + e;
+                av[q][e] = (r < rem && c < nb && base + r - (k0 + c) <= bw) ? raw[q][e] : real(0);
+            }
+        fetch_inverse(k0 + kNB, li_n);
+        fetch_rows(k0 + kNB, raw_n);
         real incoming = real(0);
         const int irow = k0 + reach + tid;
         if (tid < kNB && irow < n) incoming = b[irow];
-        __syncthreads();
-        const real ym = ys[m];
+        // y = Linv * b_panel (waves 0..3)
+        if (wave < 4) {
+            real t0 = real(0), t1 = real(0);
 #pragma unroll
-        for (int q = 0; q < kMaxQ; q++) {
-            const int r = 2 * (wave + 16 * q) + half;
-            if (2 * (16 * q) < rem) {                              // uniform over the workgroup
-                const real s = sum32(av[q] * ym);
-                if (m == 0 && r < rem) win[(base + r) & (kWin - 1)] -= s;
+            for (int e = 0; e < 4; e += 2) {
+                const int c0 = k0 + 4 * g + e;
+                t0 = fma(li[e], c0 < n ? win[c0 & (kWin - 1)] : real(0), t0);
+                t1 = fma(li[e + 1], c0 + 1 < n ? win[(c0 + 1) & (kWin - 1)] : real(0), t1);
             }
+            const real yv = sum8(t0 + t1);
+            const int r = 8 * wave + sub;
+            if (g == 0) { ys[r] = yv; if (r < nb) b[k0 + r] = yv; }
+        }
+        lds_barrier();
+#ifdef VS_CHOL_TIMING
+        unsigned long long tt1 = __builtin_readcyclecounter();
+#endif
+        const double2 y01 = reinterpret_cast<const double2 *>(ys)[2 * g], y23 = reinterpret_cast<const double2 *>(ys)[2 * g + 1];
+#pragma unroll
+        for (int q = 0; q < QN; q++) {
+            const real s = sum8(fma(av[q][0], y01.x, av[q][1] * y01.y) + fma(av[q][2], y23.x, av[q][3] * y23.y));
+            const int r = 128 * q + 8 * wave + sub;
+            if (g == 0 && r < rem) win[(base + r) & (kWin - 1)] -= s;
         }
         if (tid < kNB && irow < n) win[irow & (kWin - 1)] = incoming;
+        lds_barrier();
+#ifdef VS_CHOL_TIMING
+        if (tid == 0 && k0 == 32 * 50) printf("trsv forward panel: stage 1 %llu, stage 2 %llu (rem %d)\n", tt1 - tt0, (unsigned long long)__builtin_readcyclecounter() - tt1, rem);
+#endif
+    };
+    {
+        real liA[4], rawA[QN][4], liB[4], rawB[QN][4];
+        fetch_inverse(0, liA);
+        fetch_rows(0, rawA);
         __syncthreads();
+        for (int k0 = 0; k0 < n; k0 += 2 * kNB) {
+            forward_panel(k0, liA, rawA, liB, rawB);
+            if (k0 + kNB < n) forward_panel(k0 + kNB, liB, rawB, liA, rawA);
+        }
     }
-    // ---- backward: L^T x = y
+    // ---- backward: L^T x = y (one thread per element of the transposed block inverse, one thread
+    // per updated row and column half)
+    __syncthreads();                                   // the forward results in b are complete
+    const int r32 = tid / kNB, m = tid % kNB;
     const int k_last = ((n - 1) / kNB) * kNB;
     for (int i = max(0, k_last - bw) + tid; i < n; i += 1024) win[i & (kWin - 1)] = b[i];
-    li = Linv[(int64_t)(k_last / kNB) * kNB * kNB + m * kNB + r32];   // transposed element
+    real li = Linv[(int64_t)(k_last / kNB) * kNB * kNB + m * kNB + r32];   // transposed element
     __syncthreads();
     for (int k0 = k_last; k0 >= 0; k0 -= kNB) {
         const int nb = min(kNB, n - k0);
@@ -959,7 +1036,8 @@ __global__ void solve6_kernel(int Nc, const real *__restrict__ S_diag, const rea
 
 // Factor + solve.  A, ld, bw: storage as described at the top of this file, lower triangle
 // filled; b: rhs, overwritten with the solution; info (device int, zeroed by the caller): first
-// failing pivot + 1, or 0; Linv: device workspace of ceil(n / 32) * 32 * 32 reals.
+// failing pivot + 1, or 0; Linv: device workspace of ceil(n / 32) * 32 * 32 reals.  The storage behind A
+// must extend kNB elements past the last matrix element (the solves read whole 32-column groups).
 static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, int *info, real *Linv,
                                  hipStream_t s)
 {
@@ -984,7 +1062,10 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
         else
             hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(1024), (size_t)buf_rows * kXS * sizeof(real), s,
                                A, n, ld, bw, info, Linv);
-        hipLaunchKernelGGL(chol_trsv_window_kernel, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
+        const int turns = (window + 127) / 128;
+        if (turns <= 1) hipLaunchKernelGGL(chol_trsv_window_kernel<1>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
+        else if (turns <= 2) hipLaunchKernelGGL(chol_trsv_window_kernel<2>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
+        else hipLaunchKernelGGL(chol_trsv_window_kernel<(kFusedMaxRows + 127) / 128>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
     } else {
         for (int k0 = 0; k0 < n; k0 += kNB) {
             const int nb = n - k0 < kNB ? n - k0 : kNB;

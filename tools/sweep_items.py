@@ -15,5 +15,5 @@ print('{name} waves={waves} ept={ept}', [round(float(x)*1e3,1) for x in ms])
     subprocess.run([sys.executable, '-c', code], env=env)
 for name in sys.argv[1:]:
     for waves in (1, 4):
-        for ept in (1, 2, 3, 6):
+        for ept in (2, 3, 4, 5, 6, 8):
             run(name, waves, ept)

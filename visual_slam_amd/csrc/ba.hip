@@ -448,14 +448,17 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         bool banded = (int64_t)(band + 1) * 2 <= n;
         if (const char *e = getenv("VS_BA_SOLVER")) banded = banded && strcmp(e, "dense") != 0;   // test knob
         const int bw = banded ? band : n;
-        const int64_t ld = banded ? band : n;
-        const size_t elems = banded ? (size_t)n * (band + 1) : (size_t)n * n;
+        // Row stride padded to a multiple of 16 elements: with panels starting at multiples of 32,
+        // every 16-element row segment of a 16 x 16 tile is then exactly one aligned 128-byte line
+        // (unaligned segments leave partially written lines in L2 whose next read goes to HBM).
+        const int64_t ld = ((int64_t)(banded ? band : n) + 15) / 16 * 16;
+        const size_t elems = banded ? (size_t)n * (ld + 1) + ld : (size_t)n * ld;
         VS_CHECK(elems * sizeof(real) <= (size_t)16 << 30, VS_ERR_UNSUPPORTED,
                  "reduced system of %d cameras with camera-pair gap %d exceeds this build's solver limit (16 GiB)",
                  Nc, h->max_pair_gap);
         if (h->dense.n < elems + kNB) VS_TRY(h->dense.alloc(elems + kNB));   // padded: see cholesky_solve
         VS_HIP(hipMemsetAsync(h->dense.p, 0, (elems + kNB) * sizeof(real), s));
-        real *A = h->dense.p + (banded ? band : 0);
+        real *A = h->dense.p + (banded ? ld : 0);          // band rows reach bw <= ld elements to the left
         const int64_t ne = (int64_t)Nc * 36 + (int64_t)h->nb_off * 36;
         hipLaunchKernelGGL(assemble_lower_kernel, dim3(div_up(ne, 256)), dim3(256), 0, s, Nc, h->nb_off,
                            h->brow.p, h->bcol.p, h->S_diag(), h->S_off(), A, ld);

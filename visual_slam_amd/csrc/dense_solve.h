@@ -1,10 +1,11 @@
 // Symmetric positive-definite solve of the reduced camera system on the device: blocked
 // right-looking Cholesky (lower, in place) + triangular solves, on dense or BAND storage.
 //
-// Storage: element (i, j), j <= i, i - j <= bw, lives at A[i * ld + j].  Dense: ld = n, bw = n.
-// Band (lower half-bandwidth bw): ld = bw and A points bw elements into an n * (bw + 1) array, so
-// that row i occupies the bw + 1 consecutive slots ending at its diagonal; Cholesky fill-in stays
-// inside the band, and every kernel below touches in-band elements only.
+// Storage: element (i, j), j <= i, i - j <= bw, lives at A[i * ld + j].  Dense: ld >= n, bw = n.
+// Band (lower half-bandwidth bw): ld >= bw and A points ld elements into the array, so that row i
+// occupies the bw + 1 slots ending at A[i * (ld + 1)]; Cholesky fill-in stays inside the band, and
+// every kernel below touches in-band elements only.  The caller chooses ld as a multiple of 16
+// elements so that the 16-element row segments of the update tiles are aligned 128-byte lines.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ba_kernels.h"

@@ -419,7 +419,18 @@ merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
     float b1 = kNegInf, b2 = kNegInf;
     int pbest = 0;
     const int parts = (v.n_cand + kSub - 1) / kSub;
-    for (int p = 0; p < parts; p++) {
+    int p = 0;
+    for (; p + 8 <= parts; p += 8) {                  // eight loads in flight per thread
+        float2 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) q[u] = v.part[(p + u) * v.stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (q[u].x > b1) pbest = p + u;
+            top2_union(b1, b2, q[u].x, q[u].y);
+        }
+    }
+    for (; p < parts; p++) {
         const float2 q = v.part[p * v.stride];
         if (q.x > b1) pbest = p;
         top2_union(b1, b2, q.x, q.y);

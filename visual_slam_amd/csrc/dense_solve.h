@@ -381,24 +381,24 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
     auto lower_tiles = [&](Panel X, int base, int rem, int t0, int first, int stride) {
         const int nrt = (rem + 15) >> 4, m = nrt - t0;
         const int n_tiles = m > 0 ? m * (m + 1) / 2 : 0;
-        struct Pair { int ti[2], tj[2]; real old[2][4]; bool ok[2][4]; };
+        const int ldi = (int)ld;                                  // row offsets inside a tile fit 32 bits
+        // Index arithmetic is kept off the issue path: tiles are decoded incrementally (row a of the
+        // triangle starts at tile a (a + 1) / 2), one 64-bit address per tile, and the loads are
+        // unconditional (rows clamped into the window; the masks only guard the stores).
+        struct Pair { int ti[2], tj[2]; real *p[2]; real old[2][4]; };
+        int dec_a = 0, dec_tri = 0;
         auto fetch = [&](int t, Pair &pr) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const int tq = t + q * stride;
-                int a = (int)((sqrtf(8.0f * (float)tq + 1.0f) - 1.0f) * 0.5f);
-                while (a * (a + 1) / 2 > tq) a--;
-                while ((a + 1) * (a + 2) / 2 <= tq) a++;
-                const bool on = tq < n_tiles;
-                pr.ti[q] = on ? a + t0 : 0;
-                pr.tj[q] = on ? tq - a * (a + 1) / 2 + t0 : 0;
-                const int cc = 16 * pr.tj[q] + l15;
+                const int tq = min(t + q * stride, n_tiles - 1);      // a missing second tile repeats the last one
+                while (tq >= dec_tri + dec_a + 1) { dec_tri += dec_a + 1; dec_a++; }
+                pr.ti[q] = dec_a + t0;
+                pr.tj[q] = tq - dec_tri + t0;
+                const int r0 = 16 * pr.ti[q] + lk, r0c = min(r0, rem - 1);
+                pr.p[q] = A + (int64_t)(base + r0c) * ld + base + 16 * pr.tj[q] + l15;
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int r = 16 * pr.ti[q] + lk + 4 * v;
-                    pr.ok[q][v] = on && r < rem && cc <= r;
-                    pr.old[q][v] = pr.ok[q][v] ? A[(int64_t)(base + r) * ld + base + cc] : real(0);
-                }
+                for (int v = 0; v < 4; v++)                            // rows beyond the window read its last row
+                    pr.old[q][v] = pr.p[q][(min(r0 + 4 * v, rem - 1) - r0c) * ldi];
             }
         };
         Pair cur, nxt;
@@ -420,11 +420,13 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
                     p[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][sft], b[q][sft], p[q], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 2; q++) {
+                if (q == 1 && t + stride >= n_tiles) break;          // uniform: no second tile
                 const int cc = 16 * cur.tj[q] + l15;
+                const int r0 = 16 * cur.ti[q] + lk;
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int r = 16 * cur.ti[q] + lk + 4 * v;
-                    if (cur.ok[q][v]) A[(int64_t)(base + r) * ld + base + cc] = cur.old[q][v] - p[q][v];
+                for (int v = 0; v < 4; v++) {                          // for stored rows the clamps are no-ops
+                    const int r = r0 + 4 * v;
+                    if (r < rem && cc <= r) cur.p[q][4 * v * ldi] = cur.old[q][v] - p[q][v];
                 }
             }
             cur = nxt;

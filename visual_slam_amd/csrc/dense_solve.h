@@ -684,47 +684,40 @@ chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restri
 #ifdef VS_CHOL_TIMING
         unsigned long long st3 = __builtin_readcyclecounter();
 #endif
-        // 4. trailing update
+        // 4. trailing update.  Index arithmetic is kept off the issue path (tiles decoded
+        //    incrementally, one 64-bit address per tile, unconditional loads from rows clamped into
+        //    the window; the masks only guard the stores); the old values of a wave's next tile are
+        //    fetched before the product of the current one.
         const int n_tiles = nrt * (nrt + 1) / 2;
         {
-            // tile t of the lower triangle -> (ti, tj); the old values of a tile are fetched one
-            // turn ahead of its product
-            auto fetch = [&](int t, int &ti, int &tj, real *old, bool *ok) {
-                ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while (ti * (ti + 1) / 2 > t) ti--;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-                tj = t - ti * (ti + 1) / 2;
-                const int cc = 16 * tj + l15;
+            const int ldi = (int)ld;
+            struct Tile { int ti, tj; real *p; real old[4]; };
+            int dec_a = 0, dec_tri = 0;
+            auto fetch = [&](int t, Tile &tl) {
+                while (t >= dec_tri + dec_a + 1) { dec_tri += dec_a + 1; dec_a++; }
+                tl.ti = dec_a;
+                tl.tj = t - dec_tri;
+                const int r0 = 16 * tl.ti + lk, r0c = min(r0, rem - 1);
+                tl.p = A + (int64_t)(base + r0c) * ld + base + 16 * tl.tj + l15;
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int r = 16 * ti + lk + 4 * v;
-                    ok[v] = r < rem && cc <= r;
-                    old[v] = ok[v] ? A[(int64_t)(base + r) * ld + base + cc] : real(0);
-                }
+                for (int v = 0; v < 4; v++)                                // rows beyond the window read its last row
+                    tl.old[v] = tl.p[(min(r0 + 4 * v, rem - 1) - r0c) * ldi];
             };
-            int t = wave, ti = 0, tj = 0;
-            real old[4] = { 0, 0, 0, 0 };
-            bool ok[4] = { false, false, false, false };
-            if (t < n_tiles) fetch(t, ti, tj, old, ok);
-            while (t < n_tiles) {
+            Tile cur, nxt;
+            if (wave < n_tiles) fetch(wave, cur);
+            for (int t = wave; t < n_tiles; t += 16) {
+                if (t + 16 < n_tiles) fetch(t + 16, nxt);
                 real a[8], b[8];
-                load_frag(&X[16 * ti + l15][0], lk, a);
-                load_frag(&X[16 * tj + l15][0], lk, b);
-                const int tn = t + 16;
-                int tin = 0, tjn = 0;
-                real oldn[4] = { 0, 0, 0, 0 };
-                bool okn[4] = { false, false, false, false };
-                if (tn < n_tiles) fetch(tn, tin, tjn, oldn, okn);
+                load_frag(&X[16 * cur.ti + l15][0], lk, a);
+                load_frag(&X[16 * cur.tj + l15][0], lk, b);
                 const d4 p = frag_product(a, b);
-                const int cc = 16 * tj + l15;
+                const int cc = 16 * cur.tj + l15, r0 = 16 * cur.ti + lk;
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int r = 16 * ti + lk + 4 * v;
-                    if (ok[v]) A[(int64_t)(base + r) * ld + base + cc] = old[v] - p[v];
+                for (int v = 0; v < 4; v++) {                              // for stored rows the clamps are no-ops
+                    const int r = r0 + 4 * v;
+                    if (r < rem && cc <= r) cur.p[4 * v * ldi] = cur.old[v] - p[v];
                 }
-                t = tn; ti = tin; tj = tjn;
-#pragma unroll
-                for (int v = 0; v < 4; v++) { old[v] = oldn[v]; ok[v] = okn[v]; }
+                cur = nxt;
             }
         }
         __syncthreads();

@@ -264,8 +264,8 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         h->item_waves = avg >= 512.0 ? 4 : 1;
     }
     if (const char *e = getenv("VS_BA_ITEM_WAVES")) h->item_waves = atoi(e) == 4 ? 4 : 1;   // tuning knobs
-    int ept = h->item_waves == 4 ? 4 : 3;                  // entries per thread and item
-    if (const char *e = getenv("VS_BA_ITEM_EPT")) ept = std::max(1, atoi(e));
+    int ept = h->item_waves == 4 ? kEpt4 : kEpt1;          // entries per thread and item
+    if (const char *e = getenv("VS_BA_ITEM_EPT")) ept = std::min(ept, std::max(1, atoi(e)));
     const int ch = h->item_waves * kWave * ept;
     // Items are listed block row by block row (camera c's diagonal item(s), then its
     // off-diagonal blocks (c, c') in column order) so that a contiguous range of items is a band
@@ -362,12 +362,12 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
         const BlockItem *list = h->fix_points ? h->diag_items.p : h->items.p;
         if (n_items > 0) {
             if (h->item_waves == 4)
-                hipLaunchKernelGGL(blocks_kernel<4>, dim3(n_items), dim3(4 * kWave), 0, h->stream, n_items, list,
+                hipLaunchKernelGGL((blocks_kernel<4, kEpt4>), dim3(n_items), dim3(4 * kWave), 0, h->stream, n_items, list,
                                    h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
                                    h->Nc, h->nb_off);
             else
-                hipLaunchKernelGGL(blocks_kernel<1>, dim3(n_items), dim3(kWave), 0, h->stream, n_items, list,
+                hipLaunchKernelGGL((blocks_kernel<1, kEpt1>), dim3(n_items), dim3(kWave), 0, h->stream, n_items, list,
                                    h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
                                    h->Nc, h->nb_off);

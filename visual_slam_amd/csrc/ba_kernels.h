@@ -34,9 +34,12 @@ struct Intr {
 
 constexpr int kWave = 64;
 constexpr int kLmThreads = 256;   // landmark-major kernels: one thread per landmark
-constexpr int kRedStride = 65;    // padded row of the transposed wave reduction (conflict-free)
+constexpr int kRedStride = 67;    // row of the transposed wave reduction: 64 lanes + 2 zero cells, odd stride
+constexpr int kRedSeg = 22;       // elements one lane sums in the reduction (3 segments per row)
 constexpr int kDiagVals = 39;     // S_cc sym 21 | rhs 6 | diag(U) 6 | g_c 6
 constexpr int kOffVals = 36;      // S_ab 6x6
+constexpr int kEpt4 = 4;          // entries per thread of a 4-wave work item
+constexpr int kEpt1 = 3;          // entries per thread of a 1-wave work item
 
 // Per-observation linearisation of the reference's reprojection residual
 // (reference: src/core/reprojection_error.h:22-51; camera looks along +Y).
@@ -394,22 +397,40 @@ obs_jacobian_kernel(int No, Intr K, const CamData *__restrict__ cams, const real
 }
 
 // Transposed wave reduction: each lane holds NV partial values; lane v < NV ends up with the
-// sum over the 64 lanes of value v, summed in lane order (fixed, reproducible).  Every thread of
-// the block must call it (it synchronises the block before reusing the LDS rows).
+// sum over the 64 lanes of value v.  Three lanes share a value (22 row cells each, four
+// independent chains per lane, cells 64 and 65 of a row hold zeros), then the three partial
+// sums are added in segment order: the order is fixed, so results are reproducible, and the
+// longest dependent chain is 9 additions instead of 64.  Every thread of the block must call it
+// (it synchronises the block before reusing the LDS rows); clear_reduce_pads must have run.
 template <int NV>
 __device__ __forceinline__ real wave_reduce_transposed(const real *acc, real *lds_wave, int lane)
 {
+    static_assert(3 * NV <= kWave && 3 * kRedSeg <= kRedStride - 1, "three segments per row");
     __syncthreads();
 #pragma unroll
     for (int v = 0; v < NV; v++) lds_wave[v * kRedStride + lane] = acc[v];
     __syncthreads();
-    real s = real(0);
-    if (lane < NV) {
-        const real *row = lds_wave + lane * kRedStride;
-#pragma unroll 8
-        for (int l = 0; l < kWave; l++) s += row[l];
+    real p = real(0);
+    if (lane < 3 * NV) {
+        const int seg = lane / NV, v = lane - seg * NV;
+        const real *row = lds_wave + v * kRedStride + kRedSeg * seg;
+        real c[4] = { row[0], row[1], row[2], row[3] };
+#pragma unroll
+        for (int l = 4; l < kRedSeg; l++) c[l & 3] += row[l];
+        p = (c[0] + c[1]) + (c[2] + c[3]);
     }
-    return s;
+    const real p1 = __shfl_down(p, NV, kWave), p2 = __shfl_down(p, 2 * NV, kWave);
+    return (p + p1) + p2;
+}
+
+// Zeroes the two pad cells of every reduction row of this wave (once per kernel, before the
+// first reduction; the reductions never write them).
+__device__ __forceinline__ void clear_reduce_pads(real *lds_wave, int lane, int rows)
+{
+    if (lane < rows) {
+        lds_wave[lane * kRedStride + kWave] = real(0);
+        lds_wave[lane * kRedStride + kWave + 1] = real(0);
+    }
 }
 
 // Views into the reduce buffer
@@ -482,16 +503,18 @@ __device__ __forceinline__ void load_rec(const real *__restrict__ lmrec, int j, 
         if (i < n2) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
 }
 
-// (a)+(b), block side: one workgroup of WAVES waves per work item.
+// (a)+(b), block side: one workgroup of WAVES waves per work item of at most EPT entries per thread.
 //   diagonal items (ca == cb): a slice of one camera's observations (camera-major view).  Per
 //     observation, with N = I - Jp Vinv Jp^T (2x2; N = I when points are fixed):
 //       S_cc += Jc^T N Jc,  rhs += Jc^T (Jp Vinv g_p - r),  diag(U) += diag(Jc^T Jc),  g_c += Jc^T r
 //   off-diagonal items: a slice of the landmarks seen by both cameras a < b of one block:  S_ab -= Jc_a^T (Jp_a Vinv Jp_b^T) Jc_b.
-// r, Jc, Jp are recomputed from the parameters (J is never stored).  The next entry's landmark
-// record is loaded while the current one is processed.  A block made of a single item is written
-// straight into the reduce buffer, otherwise a per-item partial is written and finalize_kernel
-// adds the partials in item order.
-template <int WAVES>
+// r, Jc, Jp are recomputed from the parameters (J is never stored).  A thread's landmark indices
+// are all loaded up front (one memory latency for the whole item instead of one per entry), the
+// landmark record of the next entry is loaded while the current one is processed, and the entry
+// loop is unrolled so the two record buffers alternate without copies.  A block made of a single
+// item is written straight into the reduce buffer, otherwise a per-item partial is written and
+// finalize_kernel adds the partials in item order.
+template <int WAVES, int EPT>
 __global__ void __launch_bounds__(WAVES *kWave) __attribute__((amdgpu_waves_per_eu(WAVES == 1 ? 3 : 2, WAVES == 1 ? 3 : 2)))
 blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
               const CamData *__restrict__ cams, const real *__restrict__ lmrec,
@@ -505,6 +528,7 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     real *lds_wave = lds + wave * 21 * kRedStride;
     real *xw = lds + WAVES * 21 * kRedStride;
+    clear_reduce_pads(lds_wave, lane, 21);
     // XCD-aware order: workgroups sharing an XCD (blockIdx.x % 8) take one contiguous eighth of
     // the item list, i.e. a band of cameras, so the landmark records that band's blocks share
     // stay in that XCD's L2.
@@ -516,27 +540,33 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
     const BlockItem it = items[item];
     const RedView rv = red_view(red, Nc, nb_off);
     constexpr int kStride = WAVES * kWave;
+    const int k0 = it.begin + (int)threadIdx.x;
     if (it.ca == it.cb) {
+        int jx[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) jx[e] = k0 + e * kStride < it.end ? cpt[k0 + e * kStride] : -1;
         real acc[kDiagVals];
 #pragma unroll
         for (int v = 0; v < kDiagVals; v++) acc[v] = real(0);
         CamData cd;
         load_cam(cams, it.ca, cd);
-        int k = it.begin + (int)threadIdx.x;
-        bool have = k < it.end;
-        real rec[kRec], u = 0, vv = 0;
-        int j = 0;
-        if (have) { j = cpt[k]; u = cuv[2 * k]; vv = cuv[2 * k + 1]; load_rec(lmrec, j, rec, 6); }
-        while (have) {
-            const int kn = k + kStride;
-            const bool hn = kn < it.end;
-            real recn[kRec], un = 0, vn = 0;
-            int jn = 0;
-            if (hn) { jn = cpt[kn]; un = cuv[2 * kn]; vn = cuv[2 * kn + 1]; load_rec(lmrec, jn, recn, 6); }
-            const real *P = rec, *vi = rec + 3, *g = rec + 9;
+        real rec[2][kRec], uv[2][2];
+        auto fetch = [&](int e, int buf) {
+            if (jx[e] >= 0) {
+                const double2 m = *reinterpret_cast<const double2 *>(cuv + 2 * (int64_t)(k0 + e * kStride));
+                uv[buf][0] = m.x; uv[buf][1] = m.y;
+                load_rec(lmrec, jx[e], rec[buf], 6);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            if (e + 1 < EPT) fetch(e + 1, (e + 1) & 1);
+            if (jx[e] < 0) continue;
+            const real *P = rec[e & 1], *vi = P + 3, *g = P + 9;
             ObsLin o;
-            project_obs(cd, P, u, vv, K, o);
-            if (j == hub.pt && it.ca == hub.cam) scale_lin(o, *hub_w);
+            project_obs(cd, P, uv[e & 1][0], uv[e & 1][1], K, o);
+            if (jx[e] == hub.pt && it.ca == hub.cam) scale_lin(o, *hub_w);
             real Jc[12];
             camera_jac(cd, o, P, Jc);
             real n00 = real(1), n01 = real(0), n11 = real(1), e0 = -o.r0, e1 = -o.r1;
@@ -577,9 +607,6 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
                 if (p != 2) { t1 = fma(Jc[p], e0, t1); t2 = fma(Jc[p], Jc[p], t2); t3 = fma(Jc[p], o.r0, t3); }
                 acc[21 + p] = t1; acc[27 + p] = t2; acc[33 + p] = t3;
             }
-            k = kn; have = hn; j = jn; u = un; vv = vn;
-#pragma unroll
-            for (int m = 0; m < kRec; m++) rec[m] = recn[m];
         }
         const real s1 = group_reduce<21, WAVES>(acc, lds_wave, xw, lane, wave);
         const real s2 = group_reduce<18, WAVES>(acc + 21, lds_wave, xw, lane, wave);
@@ -593,29 +620,27 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
             }
         }
     } else {
+        int jx[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) jx[e] = k0 + e * kStride < it.end ? bent[k0 + e * kStride] : -1;
         real acc[kOffVals];
 #pragma unroll
         for (int v = 0; v < kOffVals; v++) acc[v] = real(0);
         CamData A, B;
         load_cam(cams, it.ca, A);
         load_cam(cams, it.cb, B);
-        int k = it.begin + (int)threadIdx.x;
-        bool have = k < it.end;
-        real rec[10];
-        int j = 0;
-        if (have) { j = bent[k]; load_rec(lmrec, j, rec, 5); }
-        while (have) {
-            const int kn = k + kStride;
-            const bool hn = kn < it.end;
-            real recn[10];
-            int jn = 0;
-            if (hn) { jn = bent[kn]; load_rec(lmrec, jn, recn, 5); }
-            const real *P = rec, *vi = rec + 3;
+        real rec[2][10];
+        if (jx[0] >= 0) load_rec(lmrec, jx[0], rec[0], 5);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            if (e + 1 < EPT) { if (jx[e + 1] >= 0) load_rec(lmrec, jx[e + 1], rec[(e + 1) & 1], 5); }
+            if (jx[e] < 0) continue;
+            const real *P = rec[e & 1], *vi = P + 3;
             ObsLin oa, ob;
             // the Jacobians do not depend on (u,v): pass zeros; only the Huber edge rescales
             project_obs(A, P, real(0), real(0), K, oa);
             project_obs(B, P, real(0), real(0), K, ob);
-            if (j == hub.pt) {
+            if (jx[e] == hub.pt) {
                 if (it.ca == hub.cam) scale_lin(oa, *hub_w);
                 if (it.cb == hub.cam) scale_lin(ob, *hub_w);
             }
@@ -651,9 +676,6 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
                     if (p != 2) t = fma(Jca[p], B0[q], t);
                     acc[6 * p + q] = t;
                 }
-            k = kn; have = hn; j = jn;
-#pragma unroll
-            for (int m = 0; m < 10; m++) rec[m] = recn[m];
         }
         const real s1 = group_reduce<18, WAVES>(acc, lds_wave, xw, lane, wave);
         const real s2 = group_reduce<18, WAVES>(acc + 18, lds_wave, xw, lane, wave);

@@ -38,8 +38,20 @@ constexpr int kRedStride = 67;    // row of the transposed wave reduction: 64 la
 constexpr int kRedSeg = 22;       // elements one lane sums in the reduction (3 segments per row)
 constexpr int kDiagVals = 39;     // S_cc sym 21 | rhs 6 | diag(U) 6 | g_c 6
 constexpr int kOffVals = 36;      // S_ab 6x6
-constexpr int kEpt4 = 4;          // entries per thread of a 4-wave work item
-constexpr int kEpt1 = 3;          // entries per thread of a 1-wave work item
+#ifndef VS_BLK_WPE1
+#define VS_BLK_WPE1 3                // waves per SIMD the 1-wave block kernel is compiled for
+#endif
+#ifndef VS_BLK_WPE4
+#define VS_BLK_WPE4 2                // same, 4-wave block kernel
+#endif
+#ifndef VS_EPT1
+#define VS_EPT1 2
+#endif
+#ifndef VS_EPT4
+#define VS_EPT4 4
+#endif
+constexpr int kEpt4 = VS_EPT4;          // entries per thread of a 4-wave work item
+constexpr int kEpt1 = VS_EPT1;          // entries per thread of a 1-wave work item
 
 // Per-observation linearisation of the reference's reprojection residual
 // (reference: src/core/reprojection_error.h:22-51; camera looks along +Y).
@@ -515,7 +527,7 @@ __device__ __forceinline__ void load_rec(const real *__restrict__ lmrec, int j, 
 // item is written straight into the reduce buffer, otherwise a per-item partial is written and
 // finalize_kernel adds the partials in item order.
 template <int WAVES, int EPT>
-__global__ void __launch_bounds__(WAVES *kWave) __attribute__((amdgpu_waves_per_eu(WAVES == 1 ? 3 : 2, WAVES == 1 ? 3 : 2)))
+__global__ void __launch_bounds__(WAVES *kWave) __attribute__((amdgpu_waves_per_eu(WAVES == 1 ? VS_BLK_WPE1 : VS_BLK_WPE4, WAVES == 1 ? VS_BLK_WPE1 : VS_BLK_WPE4)))
 blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
               const CamData *__restrict__ cams, const real *__restrict__ lmrec,
               const int *__restrict__ cpt, const real *__restrict__ cuv,
@@ -688,6 +700,29 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
     }
 }
 
+// Sum of p[it * stride] for it in [i0, i1), added in item order; the loads go out four at a time
+// (a dependent load per addition would cost one memory latency per item).
+__device__ __forceinline__ real sum_partials_strided(const real *__restrict__ p, int stride, int i0, int i1)
+{
+    real s = real(0);
+    int it = i0;
+    for (; it + 4 <= i1; it += 4) {
+        const real a = p[(int64_t)it * stride], b = p[(int64_t)(it + 1) * stride],
+                   c = p[(int64_t)(it + 2) * stride], d = p[(int64_t)(it + 3) * stride];
+        s += a; s += b; s += c; s += d;
+    }
+    const int left = i1 - it;
+    if (left > 0) {
+        const real a = p[(int64_t)it * stride];
+        const real b = left > 1 ? p[(int64_t)(it + 1) * stride] : real(0);
+        const real c = left > 2 ? p[(int64_t)(it + 2) * stride] : real(0);
+        s += a;
+        if (left > 1) s += b;
+        if (left > 2) s += c;
+    }
+    return s;
+}
+
 // Fixed-order sum of the per-item partials of multi-item blocks into the reduce buffer, and of
 // the landmark kernel's cost partials.  nb_off fixes the buffer layout; only the first nb_sum
 // off-diagonal blocks are touched (0 when points are fixed).  Diagonal damping is NOT applied
@@ -713,17 +748,13 @@ finalize_kernel(int Nc, int nb_off, int nb_sum, const int *__restrict__ diag_ite
         const int c = (int)(tid / kDiagVals), v = (int)(tid % kDiagVals);
         const int i0 = diag_item_ptr[c], i1 = diag_item_ptr[c + 1];
         if (i1 - i0 == 1) return;                      // written by blocks_kernel
-        real s = real(0);
-        for (int it = i0; it < i1; it++) s += diag_partial[(int64_t)it * kDiagVals + v];
-        store_diag_value(rv, c, v, s);
+        store_diag_value(rv, c, v, sum_partials_strided(diag_partial + v, kDiagVals, i0, i1));
     } else if (tid < n_diag + (int64_t)nb_sum * kOffVals) {
         const int64_t u = tid - n_diag;
         const int blk = (int)(u / kOffVals), v = (int)(u % kOffVals);
         const int i0 = off_item_ptr[blk], i1 = off_item_ptr[blk + 1];
         if (i1 - i0 == 1) return;
-        real s = real(0);
-        for (int it = i0; it < i1; it++) s += off_partial[(int64_t)it * kOffVals + v];
-        rv.S_off[(int64_t)blk * 36 + v] = s;
+        rv.S_off[(int64_t)blk * 36 + v] = sum_partials_strided(off_partial + v, kOffVals, i0, i1);
     }
 }
 

@@ -30,9 +30,19 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kD = VS_DESC_DIM;        // 256
-constexpr int kBM = 128, kBN = 128;    // workgroup tile
-constexpr int kBK = 64;                // halfs per K-step (one ring stage)
-constexpr int kRing = 2;               // LDS ring stages (kRing - 1 K-steps of lookahead)
+#ifndef VS_WAVE_ROWS
+#define VS_WAVE_ROWS 4
+#endif
+constexpr int kWR = VS_WAVE_ROWS, kWC = 4 / kWR;   // the 4 waves of a workgroup as kWR x kWC sub-tiles of 64 x 64
+constexpr int kBM = 64 * kWR, kBN = 64 * kWC;      // workgroup tile
+#ifndef VS_BK
+#define VS_BK 64
+#endif
+constexpr int kBK = VS_BK;             // halfs per K-step (one ring stage)
+#ifndef VS_RING
+#define VS_RING 2
+#endif
+constexpr int kRing = VS_RING;         // LDS ring stages (kRing - 1 K-steps of lookahead)
 constexpr int kSub = 64;               // rows/cols covered by one wave = granularity of partials
 constexpr float kScale = 256.0f;       // descriptor prescale (2^8), dot prescale 2^16
 constexpr float kDotScale = 65536.0f;
@@ -137,13 +147,18 @@ struct PairDims {
 constexpr int kStageBytes = kBN * kBK * 2;
 constexpr int kChunksPerRow = kBK / 8;                  // 16-byte chunks per image row
 constexpr int kRowsPerDma = 64 / kChunksPerRow;         // image rows per DMA wave-instruction
-constexpr int kDmaPerWave = 32 / kRowsPerDma;           // DMA instructions per wave and stage
-constexpr int kSwzShift = kBK == 64 ? 1 : 2;            // log2(rows per 256-byte bank line)
+constexpr int kRowsPerWave = kBN / 4;                   // image rows one wave fills per stage
+constexpr int kDmaPerWave = kRowsPerWave / kRowsPerDma; // DMA instructions per wave and stage
+constexpr int kSwzShift = kBK == 128 ? 0 : (kBK == 64 ? 1 : 2);   // log2(rows per 256-byte bank line)
 constexpr int kInflight = (kRing - 2) * kDmaPerWave;    // DMAs allowed in flight behind stage s
-static_assert(kBK == 32 || kBK == 64, "swizzle is written for 64- and 128-byte image rows");
+static_assert(kBK == 32 || kBK == 64 || kBK == 128, "swizzle is written for 64-, 128- and 256-byte image rows");
 __device__ __forceinline__ int stage_swizzle(int row) { return (row >> kSwzShift) & (kChunksPerRow - 1); }
 constexpr int kTS = 68;                                 // transpose row stride in floats
+#ifdef VS_EXP_NO_EPILOGUE
+constexpr int kDotLds = kRing * kStageBytes;
+#else
 constexpr int kDotLds = kRing * kStageBytes + 4 * 32 * kTS * 4;
+#endif
 static_assert(2 * kDotLds <= 160 * 1024, "two workgroups per CU");
 
 // One workgroup = one band: kBM rows of desc0 of one frame pair against `tiles_per_wg` consecutive
@@ -153,6 +168,20 @@ static_assert(2 * kDotLds <= 160 * 1024, "two workgroups per CU");
 // K-step (also across tile boundaries) in flight behind the MFMAs and the epilogue of the current
 // one.  Epilogue: per-column top-2 over the wave's 64 rows (in registers) and per-row top-2 over
 // its 64 columns (transposed through a wave-private LDS area, no barrier).
+#ifdef VS_MATCH_STAMPS      // timeline instrumentation build: cycle stamps of one workgroup's first tiles
+__device__ unsigned long long g_match_stamps[4 * 64];
+#define VS_STAMP()                                                                              \
+    do {                                                                                        \
+        if (stamp_on && n_stamp < 64) {                                                         \
+            const unsigned long long t_ = __builtin_readcyclecounter();                         \
+            if (lane == 0) s_stamps[wave * 64 + n_stamp] = t_;                                  \
+            n_stamp++;                                                                          \
+        }                                                                                       \
+    } while (0)
+#else
+#define VS_STAMP() do { } while (0)
+#endif
+
 template <bool MASKED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b16,
@@ -163,7 +192,12 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
     __shared__ __attribute__((aligned(16))) unsigned char smem[kDotLds];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+#ifdef VS_MATCH_STAMPS
+    __shared__ unsigned long long s_stamps[4 * 64];
+    const bool stamp_on = blockIdx.x == gridDim.x / 2 + 8;
+    int n_stamp = 0;
+#endif
+    const int wr = wave / kWC, wc = wave % kWC;
     const int half = lane >> 5, l31 = lane & 31;
 
     // band decode; workgroups that share an XCD (blockIdx.x % 8) take a contiguous range of
@@ -203,7 +237,7 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
     int src_off[kDmaPerWave];
 #pragma unroll
     for (int q = 0; q < kDmaPerWave; q++) {
-        const int row = wave * 32 + q * kRowsPerDma + lane / kChunksPerRow;
+        const int row = wave * kRowsPerWave + q * kRowsPerDma + lane / kChunksPerRow;
         src_off[q] = row * kD + (((lane % kChunksPerRow) ^ stage_swizzle(row)) * 8);
     }
     const _Float16 *gB = b16 + (int64_t)pair * n1_pad * kD;
@@ -213,7 +247,7 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
     do {                                                                                       \
         const int st_ = (s_);                                                                  \
         const _Float16 *g_ = gB + (int64_t)(c_begin + st_ / kStepsPerTile) * kBN * kD + (st_ % kStepsPerTile) * kBK; \
-        unsigned char *l_ = smem + (st_ % kRing) * kStageBytes + wave * (32 * kBK * 2);        \
+        unsigned char *l_ = smem + (st_ % kRing) * kStageBytes + wave * (kRowsPerWave * kBK * 2);        \
         _Pragma("unroll") for (int q_ = 0; q_ < kDmaPerWave; q_++)                             \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_ + src_off[q_]), \
                                              (__attribute__((address_space(3))) void *)(l_ + q_ * 1024), 16, 0, 0); \
@@ -230,6 +264,7 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         if (st < n_stages) VS_ISSUE_STAGE(st);
     for (int tc = c_begin; tc < c_end; tc++) {
     const int j0 = tc * kBN;
+    VS_STAMP();
     f32x16 acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -250,24 +285,36 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInflight) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        VS_STAMP();
         if (s + kRing - 1 < n_stages) VS_ISSUE_STAGE(s + kRing - 1);
         const unsigned char *buf = smem + (s % kRing) * kStageBytes + frag_row;
+        // desc1 fragments of sub-step ks + 1 are read while the MFMAs of sub-step ks run (two
+        // register sets), so one LDS latency is exposed per K-step, not one per sub-step
+        half8 bf[2][2];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+            bf[0][n] = *reinterpret_cast<const half8 *>(buf + n * 32 * (kBK * 2) + ((half ^ swz) * 16));
 #pragma unroll
         for (int ks = 0; ks < kBK / 16; ks++) {
-            half8 bf[2];
+            if (ks + 1 < kBK / 16) {
 #pragma unroll
-            for (int n = 0; n < 2; n++)
-                bf[n] = *reinterpret_cast<const half8 *>(buf + n * 32 * (kBK * 2) + (((2 * ks + half) ^ swz) * 16));
+                for (int n = 0; n < 2; n++)
+                    bf[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(buf + n * 32 * (kBK * 2) + (((2 * (ks + 1) + half) ^ swz) * 16));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < 2; n++)
 #ifndef VS_EXP_NO_MFMA      // ablation build (wrong results) when defined: everything but the MFMAs
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][kt * (kBK / 16) + ks], bf[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][kt * (kBK / 16) + ks], bf[ks & 1][n], acc[m][n], 0, 0, 0);
 #else
-                    acc[m][n][0] += (float)bf[n][0] + (float)af[m][kt * (kBK / 16) + ks][0];
+                    acc[m][n][0] += (float)bf[ks & 1][n][0] + (float)af[m][kt * (kBK / 16) + ks][0];
 #endif
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        VS_STAMP();
     }
 
 #ifdef VS_EXP_NO_EPILOGUE   // ablation build (wrong results): times the K loop without the top-2 epilogue
@@ -338,6 +385,8 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
             col_part[o] = make_float2(b1, b2);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    VS_STAMP();
     // rows: transpose 32 rows x 64 cols at a time through the wave's own LDS area (row stride 68
     // floats keeps the float4 reads aligned and conflict-free; a wave's LDS operations complete in
     // issue order, so no barrier is needed); position code = column inside the wave's 64
@@ -363,7 +412,13 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
             row_part[o] = make_float2(b1, b2);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    VS_STAMP();
     }   // column tiles of the band
+#ifdef VS_MATCH_STAMPS
+    if (stamp_on && lane == 0)
+        for (int i = 0; i < 64; i++) g_match_stamps[wave * 64 + i] = i < n_stamp ? s_stamps[wave * 64 + i] : 0ull;
+#endif
 #undef VS_TOP2_STEP
 #undef VS_ISSUE_STAGE
 }
@@ -962,3 +1017,10 @@ int vs_match_stereo(const float *desc0, const int32_t *xy0, int32_t n0, const fl
 }
 
 }  // extern "C"
+
+#ifdef VS_MATCH_STAMPS
+extern "C" int vs_debug_match_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_stamps), sizeof(unsigned long long) * 4 * 64);
+}
+#endif

@@ -36,7 +36,7 @@ constexpr int kD = VS_DESC_DIM;        // 256
 constexpr int kWR = VS_WAVE_ROWS, kWC = 4 / kWR;   // the 4 waves of a workgroup as kWR x kWC sub-tiles of 64 x 64
 constexpr int kBM = 64 * kWR, kBN = 64 * kWC;      // workgroup tile
 #ifndef VS_BK
-#define VS_BK 64
+#define VS_BK 128
 #endif
 constexpr int kBK = VS_BK;             // halfs per K-step (one ring stage)
 #ifndef VS_RING

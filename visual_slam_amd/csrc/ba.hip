@@ -130,7 +130,8 @@ int prep_cameras(vs_ba *h, const real *t, const real *rpy)
     return launch_check("prep_cameras");
 }
 
-size_t cam_lds_bytes(const vs_ba *h) { return h->stage_cams ? (size_t)h->Nc * sizeof(CamData) : 0; }
+// camera records, plus the sines and cosines the landmark kernel keeps behind them
+size_t cam_lds_bytes(const vs_ba *h) { return h->stage_cams ? (size_t)h->Nc * (sizeof(CamData) + 6 * sizeof(real)) : 0; }
 
 // Builds every index structure from the caller's edge list (host side, once per edge set).
 int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const double *uv)
@@ -296,7 +297,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     h->n_off_items = n_off_items;
     h->n_lm_blocks = div_up(Np, kLmThreads);
     h->n_lm4_blocks = div_up(Np, kLmPerBlock);
-    h->stage_cams = (size_t)Nc * sizeof(CamData) <= 48 * 1024;
+    h->stage_cams = (size_t)Nc * (sizeof(CamData) + 6 * sizeof(real)) <= 48 * 1024;
 
     hipStream_t s = h->stream;
     VS_TRY(h->pt_ptr.upload(pt_ptr.data(), pt_ptr.size(), s));

@@ -163,12 +163,9 @@ __device__ __forceinline__ void load_cam(const CamData *cams, int c, CamData &ou
 // ---------------------------------------------------------------------------------------------
 // Camera record of camera c from its parameters: R = Rz(yaw) Ry(pitch) Rx(roll)
 // (reference: src/core/reprojection_error.h:32-35).
-__device__ __forceinline__ CamData make_cam(const real *__restrict__ t, const real *__restrict__ rpy, int c)
+__device__ __forceinline__ CamData cam_from_sincos(const real *__restrict__ t, int c, real sr, real cr,
+                                                   real sp, real cp, real sy, real cy)
 {
-    real sr, cr, sp, cp, sy, cy;
-    sincos(rpy[3 * c], &sr, &cr);
-    sincos(rpy[3 * c + 1], &sp, &cp);
-    sincos(rpy[3 * c + 2], &sy, &cy);
     CamData d;
     d.R[0] = cy * cp; d.R[1] = cy * sp * sr - sy * cr; d.R[2] = cy * sp * cr + sy * sr;
     d.R[3] = sy * cp; d.R[4] = sy * sp * sr + cy * cr; d.R[5] = sy * sp * cr - cy * sr;
@@ -176,6 +173,15 @@ __device__ __forceinline__ CamData make_cam(const real *__restrict__ t, const re
     d.t[0] = t[3 * c]; d.t[1] = t[3 * c + 1]; d.t[2] = t[3 * c + 2];
     d.sy = sy; d.cy = cy; d.pad[0] = d.pad[1] = real(0);
     return d;
+}
+
+__device__ __forceinline__ CamData make_cam(const real *__restrict__ t, const real *__restrict__ rpy, int c)
+{
+    real sr, cr, sp, cp, sy, cy;
+    sincos(rpy[3 * c], &sr, &cr);
+    sincos(rpy[3 * c + 1], &sp, &cp);
+    sincos(rpy[3 * c + 2], &sy, &cy);
+    return cam_from_sincos(t, c, sr, cr, sp, cp, sy, cy);
 }
 
 __global__ void prep_cameras_kernel(int Nc, const real *__restrict__ t,
@@ -224,8 +230,9 @@ constexpr int kLmPerBlock = kLmThreads / kLpl;        // landmarks per workgroup
 // (a)+(b), landmark side.  Four lanes per landmark j share its observations:
 // V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
 // Cameras come from LDS when they fit (STAGE_CAMS).  With prep_t / prep_rpy given (STAGE_CAMS only)
-// every workgroup builds the camera records itself, straight into LDS, and workgroup 0 also
-// stores them to `cams_out` for the kernels that follow: no separate camera pass.
+// every workgroup builds the camera records itself, straight into LDS (which then also holds
+// 6 Nc reals of sines and cosines behind the records), and workgroup 0 also stores them to
+// `cams_out` for the kernels that follow: no separate camera pass.
 template <bool STAGE_CAMS>
 __global__ void __launch_bounds__(kLmThreads)
 landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
@@ -239,10 +246,24 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     CamData *scams = reinterpret_cast<CamData *>(smem_raw);
     __shared__ real red[4];
+    // the landmark's own data first: these loads are in flight while the cameras are staged
+    const int j = blockIdx.x * kLmPerBlock + ((int)threadIdx.x >> 2);
+    const int sl = threadIdx.x & (kLpl - 1);
+    real P[3] = { 0, 0, 0 };
+    int b = 0, e = 0;
+    if (j < Np) {
+        b = pt_ptr[j]; e = pt_ptr[j + 1];
+        P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
+    }
     if (STAGE_CAMS) {
         if (prep_t) {
+            // one sincos per thread (3 Nc of them) instead of three per camera in a single wave
+            real *sc = reinterpret_cast<real *>(scams + Nc);
+            for (int i = threadIdx.x; i < 3 * Nc; i += blockDim.x) sincos(prep_rpy[i], &sc[2 * i], &sc[2 * i + 1]);
+            __syncthreads();
             for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
-                const CamData d = make_cam(prep_t, prep_rpy, c);
+                const real *q = sc + 6 * c;
+                const CamData d = cam_from_sincos(prep_t, c, q[0], q[1], q[2], q[3], q[4], q[5]);
                 scams[c] = d;
                 if (blockIdx.x == 0) cams_out[c] = d;
             }
@@ -253,22 +274,25 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
         }
         __syncthreads();
     }
-    const int j = blockIdx.x * kLmPerBlock + ((int)threadIdx.x >> 2);
-    const int sl = threadIdx.x & (kLpl - 1);
     real acc[10];                                      // V (6), g (3), cost
 #pragma unroll
     for (int v = 0; v < 10; v++) acc[v] = real(0);
-    real P[3] = { 0, 0, 0 };
-    int b = 0, e = 0;
     if (j < Np) {
-        b = pt_ptr[j]; e = pt_ptr[j + 1];
-        P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
-        for (int pos = b + sl; pos < e; pos += kLpl) {
-            const int c = lcam[pos];
+        // the next observation's camera index and pixel are fetched while this one is processed
+        int pos = b + sl, c_next = 0;
+        double2 uv_next = make_double2(0, 0);
+        if (pos < e) { c_next = lcam[pos]; uv_next = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)pos); }
+        for (; pos < e; pos += kLpl) {
+            const int c = c_next;
+            const double2 uv = uv_next;
+            if (pos + kLpl < e) {
+                c_next = lcam[pos + kLpl];
+                uv_next = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(pos + kLpl));
+            }
             CamData cd;
             if (STAGE_CAMS) cd = scams[c]; else load_cam(cams, c, cd);
             ObsLin o;
-            project_obs(cd, P, luv[2 * pos], luv[2 * pos + 1], K, o);
+            project_obs(cd, P, uv.x, uv.y, K, o);
             real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
             if (pos == hub.pos) {
                 const real w = huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);

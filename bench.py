@@ -303,6 +303,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal of the N>1 path on a box with fewer GPUs than ranks: VS_BENCH_BACKEND=gloo lets the
+    # ranks share devices (RCCL refuses two ranks on one GPU); the driver's runs use nccl = RCCL
+    backend = os.environ.get("VS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_dist:
@@ -310,7 +315,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ba = bench_ba(args, rank, world, dist, torch)
     extra = {}
     if not args.no_extra:

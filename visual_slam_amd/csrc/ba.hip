@@ -293,6 +293,28 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         }
         for (int kk = 0; kk < nb_off; kk++) oi_ptr[kk + 1] = std::max(oi_ptr[kk + 1], oi_ptr[kk]);
     }
+    // The block kernel gives workgroups with equal blockIdx % 8 one contiguous eighth of the list
+    // and the hardware starts workgroups in blockIdx order: put each eighth's share of the
+    // (heavier) diagonal items at its front so that they never sit in the last round.  Only with
+    // the few large items of the 4-wave form: with many small items the last round is short anyway
+    // and keeping a camera's diagonal item next to its row of blocks is worth more (measured).
+    if (h->item_waves == 4 && !items.empty()) {
+        std::vector<BlockItem> dg, off;
+        for (const BlockItem &it : items) (it.ca == it.cb ? dg : off).push_back(it);
+        const size_t n = items.size(), q = n / 8, r = n % 8;
+        size_t id = 0, io = 0, pos = 0;
+        for (size_t x = 0; x < 8; x++) {
+            const size_t len = q + (x < r ? 1 : 0);
+            size_t nd = dg.size() / 8 + (x < dg.size() % 8 ? 1 : 0);
+            nd = std::min(nd, len);
+            // off-diagonal items left over when the diagonal share does not fit go to later eighths
+            for (size_t i = 0; i < nd; i++) items[pos++] = dg[id++];
+            for (size_t i = nd; i < len; i++) {
+                if (io < off.size()) items[pos++] = off[io++];
+                else items[pos++] = dg[id++];
+            }
+        }
+    }
     h->n_diag_items = n_diag_items;
     h->n_off_items = n_off_items;
     h->n_lm_blocks = div_up(Np, kLmThreads);

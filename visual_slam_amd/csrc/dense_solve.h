@@ -344,6 +344,69 @@ __device__ __forceinline__ int potrf_inverse_wave(const real (*Wn)[kNB + 1], int
     return bad;
 }
 
+// Window update  A[base + r][base + c] -= X[r] . X[c]  over the 16 x 16 tiles (ti, tj), ti >= tj >= t0,
+// of the lower triangle of a window of `rem` rows, numbered t = 0, 1, ...; the calling wave takes
+// tiles first, first + stride, ... two at a time, and fetches the old values of its next two
+// tiles before it works on the current two (the read-modify-write of the window is bound by the
+// latency of those loads, not by the products).  X: panel image in LDS (rows beyond rem zero).
+__device__ __forceinline__ void update_lower_tiles(real *__restrict__ A, int64_t ld, const real (*X)[kXS],
+                                                   int base, int rem, int t0, int first, int stride, int lane)
+{
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int nrt = (rem + 15) >> 4, m = nrt - t0;
+    const int n_tiles = m > 0 ? m * (m + 1) / 2 : 0;
+    const int ldi = (int)ld;                                  // row offsets inside a tile fit 32 bits
+    // Index arithmetic is kept off the issue path: tiles are decoded incrementally (row a of the
+    // triangle starts at tile a (a + 1) / 2), one 64-bit address per tile, and the loads are
+    // unconditional (rows clamped into the window; the masks only guard the stores).
+    struct Pair { int ti[2], tj[2]; real *p[2]; real old[2][4]; };
+    int dec_a = 0, dec_tri = 0;
+    auto fetch = [&](int t, Pair &pr) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int tq = min(t + q * stride, n_tiles - 1);      // a missing second tile repeats the last one
+            while (tq >= dec_tri + dec_a + 1) { dec_tri += dec_a + 1; dec_a++; }
+            pr.ti[q] = dec_a + t0;
+            pr.tj[q] = tq - dec_tri + t0;
+            const int r0 = 16 * pr.ti[q] + lk, r0c = min(r0, rem - 1);
+            pr.p[q] = A + (int64_t)(base + r0c) * ld + base + 16 * pr.tj[q] + l15;
+#pragma unroll
+            for (int v = 0; v < 4; v++)                            // rows beyond the window read its last row
+                pr.old[q][v] = pr.p[q][(min(r0 + 4 * v, rem - 1) - r0c) * ldi];
+        }
+    };
+    Pair cur, nxt;
+    if (first < n_tiles) fetch(first, cur);
+    for (int t = first; t < n_tiles; t += 2 * stride) {
+        const int tn = t + 2 * stride;
+        if (tn < n_tiles) fetch(tn, nxt);
+        real a[2][8], b[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            load_frag(&X[16 * cur.ti[q] + l15][0], lk, a[q]);
+            load_frag(&X[16 * cur.tj[q] + l15][0], lk, b[q]);
+        }
+        d4 p[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#pragma unroll
+        for (int sft = 0; sft < 8; sft++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                p[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][sft], b[q][sft], p[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (q == 1 && t + stride >= n_tiles) break;          // uniform: no second tile
+            const int cc = 16 * cur.tj[q] + l15;
+            const int r0 = 16 * cur.ti[q] + lk;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {                          // for stored rows the clamps are no-ops
+                const int r = r0 + 4 * v;
+                if (r < rem && cc <= r) cur.p[q][4 * v * ldi] = cur.old[q][v] - p[q][v];
+            }
+        }
+        cur = nxt;
+    }
+}
+
 constexpr int kCholThreads = 512, kCholWaves = kCholThreads / 64;   // 8 waves: 256 VGPRs each
 
 // Whole factorisation in one workgroup of 8 waves, for windows of up to kLookaheadMaxRows rows (two
@@ -374,63 +437,8 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
     if (tid == 0) bad_s = 0;
 
-    // tiles (ti, tj) with ti >= tj >= t0 of a window of nrt tile rows, numbered t = 0, 1, ...; a
-    // wave takes tiles first, first + stride, ... two at a time, and fetches the old values of its
-    // next two tiles before it works on the current two (the read-modify-write of the window is
-    // bound by the latency of those loads, not by the products)
     auto lower_tiles = [&](Panel X, int base, int rem, int t0, int first, int stride) {
-        const int nrt = (rem + 15) >> 4, m = nrt - t0;
-        const int n_tiles = m > 0 ? m * (m + 1) / 2 : 0;
-        const int ldi = (int)ld;                                  // row offsets inside a tile fit 32 bits
-        // Index arithmetic is kept off the issue path: tiles are decoded incrementally (row a of the
-        // triangle starts at tile a (a + 1) / 2), one 64-bit address per tile, and the loads are
-        // unconditional (rows clamped into the window; the masks only guard the stores).
-        struct Pair { int ti[2], tj[2]; real *p[2]; real old[2][4]; };
-        int dec_a = 0, dec_tri = 0;
-        auto fetch = [&](int t, Pair &pr) {
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int tq = min(t + q * stride, n_tiles - 1);      // a missing second tile repeats the last one
-                while (tq >= dec_tri + dec_a + 1) { dec_tri += dec_a + 1; dec_a++; }
-                pr.ti[q] = dec_a + t0;
-                pr.tj[q] = tq - dec_tri + t0;
-                const int r0 = 16 * pr.ti[q] + lk, r0c = min(r0, rem - 1);
-                pr.p[q] = A + (int64_t)(base + r0c) * ld + base + 16 * pr.tj[q] + l15;
-#pragma unroll
-                for (int v = 0; v < 4; v++)                            // rows beyond the window read its last row
-                    pr.old[q][v] = pr.p[q][(min(r0 + 4 * v, rem - 1) - r0c) * ldi];
-            }
-        };
-        Pair cur, nxt;
-        if (first < n_tiles) fetch(first, cur);
-        for (int t = first; t < n_tiles; t += 2 * stride) {
-            const int tn = t + 2 * stride;
-            if (tn < n_tiles) fetch(tn, nxt);
-            real a[2][8], b[2][8];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                load_frag(&X[16 * cur.ti[q] + l15][0], lk, a[q]);
-                load_frag(&X[16 * cur.tj[q] + l15][0], lk, b[q]);
-            }
-            d4 p[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-#pragma unroll
-            for (int sft = 0; sft < 8; sft++)
-#pragma unroll
-                for (int q = 0; q < 2; q++)
-                    p[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][sft], b[q][sft], p[q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                if (q == 1 && t + stride >= n_tiles) break;          // uniform: no second tile
-                const int cc = 16 * cur.tj[q] + l15;
-                const int r0 = 16 * cur.ti[q] + lk;
-#pragma unroll
-                for (int v = 0; v < 4; v++) {                          // for stored rows the clamps are no-ops
-                    const int r = r0 + 4 * v;
-                    if (r < rem && cc <= r) cur.p[q][4 * v * ldi] = cur.old[q][v] - p[q][v];
-                }
-            }
-            cur = nxt;
-        }
+        update_lower_tiles(A, ld, X, base, rem, t0, first, stride, lane);
     };
     auto panel_rows = [&](int k0) { return max(0, min(n - (k0 + min(kNB, n - k0)), bw)); };
 
@@ -566,55 +574,50 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
     if (tid == 0 && bad_s && *info == 0) *info = bad_s;
 }
 
-// Column j of the 32 x 32 block has received its last update: its 32 owners (one half-wave, lane
-// bi = row) read the pivot from the diagonal owner's lane, scale the column by 1 / sqrt(pivot) and
-// publish the finished factor column (zero above the diagonal).  A non-positive pivot is
-// recorded (first one wins) and replaced by 1.  Returns the owner's factor entry L[bi][j].
-__device__ __forceinline__ real publish_column(real w, int j, int bi, int lane, int k0,
-                                               real *__restrict__ col, real *__restrict__ rsv,
-                                               int *__restrict__ bad)
-{
-    const int src = (lane & 32) | j;
-    real d = __shfl(w, src, 64);
-    if (!(d > real(0))) {
-        if (bi == j && *bad == 0) *bad = k0 + j + 1;
-        d = real(1);
-        if (bi == j) w = real(1);
-    }
-    const real rs = rsqrt_refined(d);
-    const real l = bi >= j ? w * rs : real(0);
-    col[bi] = l;
-    if (bi == j) rsv[j] = rs;
-    return l;
-}
-
-// Single-workgroup factorisation for windows too wide for two panel buffers (16 waves, no
-// look-ahead).  Per 32-column panel:
-//   1. the diagonal block goes to registers (one element per thread), the panel rows below it to
-//      LDS (zero outside the band and beyond the matrix);
-//   2. 32 column steps, one barrier each, factor the block and invert the factor: a step reads the
-//      finished column c (published by its owners in the previous step) and the reciprocal square
-//      root of its pivot (computed by the pivot's owner alone), updates the columns to its right in
-//      registers, and advances the forward substitution F Y = I by one row;
-//   3. X = A_panel * L_kk^-T  on the matrix cores (one 16-row tile per wave and turn);
-//   4. trailing update of the bw x bw window, 16 x 16 tiles of the lower triangle dealt to the
-//      16 waves.
+// Single-workgroup factorisation for windows too wide for two panel buffers (8 waves, one panel
+// image in LDS).  Per 32-column panel (its diagonal block already factored and inverted):
+//   1. the factor block and its inverse go to global memory, the panel rows below the block to LDS
+//      (zero outside the band and beyond the matrix);
+//   2. X = A_panel * L_kk^-T  on the matrix cores (one 16-row tile per wave and turn);
+//   3. the three 16 x 16 tiles of the window update that make up the NEXT diagonal block;
+//   4. wave 0 reads that block back and factors + inverts it in registers (potrf_inverse_wave)
+//      while the other seven waves apply the rest of the window update.
 // No launches between panels; the window lives in L2.  The block inverses are kept for the
 // triangular solves.
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(kCholThreads)
 chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restrict__ info,
                   real *__restrict__ Linv)
 {
-    __shared__ real colb[kNB][kNB];                              // colb[c][i] = column c, row i, final
+    __shared__ real Wn[kNB][kNB + 1];                            // diagonal block being factored
+    __shared__ real Ld[kNB][kNB + 1];                            // Ld[c][i] = L[i][c]
+    __shared__ __attribute__((aligned(16))) real wimg[48 * kSS];  // scratch of the factoring wave
     __shared__ __attribute__((aligned(16))) real Li[kNB][kXS];    // inverse of the block's factor
-    __shared__ real rsv[kNB];                                     // 1 / sqrt(pivot c)
     __shared__ int bad_s;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     real (*X)[kXS] = reinterpret_cast<real (*)[kXS]>(dyn_lds);
     const int tid = threadIdx.x;
-    const int bi = tid % kNB, bj = tid / kNB;
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
     if (tid == 0) bad_s = 0;
+    // wave 0: diagonal block at k0 (nb columns, identity beyond) from global memory, factor, inverse
+    auto factor_block = [&](int k0, int nb) {
+        // lane (bj = lane % 32, rows lane / 32 + 2 q): 16 unconditional loads in flight (rows and
+        // columns clamped into the block), masked when stored
+        const int bj = lane % kNB, r0 = lane / kNB;
+        const real *col = A + (int64_t)k0 * ld + k0 + min(bj, nb - 1);
+        real v[kNB / 2];
+#pragma unroll
+        for (int q = 0; q < kNB / 2; q++) v[q] = col[(int64_t)min(r0 + 2 * q, nb - 1) * ld];
+#pragma unroll
+        for (int q = 0; q < kNB / 2; q++) {
+            const int bi = r0 + 2 * q;
+            Wn[bi][bj] = (bi < nb && bj <= bi) ? v[q] : (bi == bj ? real(1) : real(0));
+        }
+        const int bad = potrf_inverse_wave(Wn, lane, wimg, Ld, Li);   // a wave's LDS operations are ordered
+        if (lane == 0 && bad && bad_s == 0) bad_s = k0 + bad;
+    };
+    __syncthreads();
+    if (wave == 0) factor_block(0, min(kNB, n));
+    __syncthreads();
     for (int k0 = 0; k0 < n; k0 += kNB) {
         const int nb = min(kNB, n - k0);
         const int base = k0 + nb;
@@ -624,46 +627,40 @@ chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restri
 #ifdef VS_CHOL_TIMING
         unsigned long long st0 = __builtin_readcyclecounter();
 #endif
-        // 1. thread (bi, bj) owns element (bi, bj) of the block (identity beyond nb); a column is one
-        //    half-wave, so its pivot reaches the column's 32 owners by a lane read
-        real w = (bi < nb && bj <= bi) ? A[(int64_t)(k0 + bi) * ld + k0 + bj] : (bi == bj ? real(1) : real(0));
-        real y = bi == bj ? real(1) : real(0);                    // forward substitution on I
-        real f = real(0), la_prev = real(0);
-        if (bj == 0) f = publish_column(w, 0, bi, lane, k0, colb[0], rsv, &bad_s);
-        for (int e = tid; e < nrt * 16 * kNB; e += 1024) {
+        // 1. factor block and inverse out, panel rows in
+        for (int e = tid; e < kNB * kNB; e += kCholThreads) {
             const int r = e / kNB, c = e % kNB;
-            const int i = base + r;
-            X[r][c] = (r < rem && c < nb && i - (k0 + c) <= bw) ? A[(int64_t)i * ld + k0 + c] : real(0);
+            if (r >= c && r < nb) A[(int64_t)(k0 + r) * ld + k0 + c] = Ld[c][r];
+            Lp[e] = Li[r][c];
+        }
+        if (rem <= 0) break;                                      // uniform: last panel
+        {
+            // thread (r0, c) reads column c of rows r0, r0 + 16, ...: four unconditional loads (rows
+            // clamped into the panel) in flight, masked when stored
+            const int c = tid % kNB, r0 = tid / kNB;
+            const real *col = A + (int64_t)base * ld + k0 + min(c, nb - 1);
+            for (int rb = 0; rb < nrt * 16; rb += 64) {
+                real v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = col[(int64_t)min(rb + 16 * q + r0, rem - 1) * ld];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = rb + 16 * q + r0;
+                    if (r < nrt * 16)
+                        X[r][c] = (r < rem && c < nb && base + r - (k0 + c) <= bw) ? v[q] : real(0);
+                }
+            }
         }
         __syncthreads();
 #ifdef VS_CHOL_TIMING
         unsigned long long st1 = __builtin_readcyclecounter();
 #endif
-        // 2. column steps
-        for (int c = 0; c < kNB; c++) {
-            const real la = colb[c][bi], lb = colb[c][bj];        // L[bi][c], L[bj][c]
-            if (bj > c && bj <= bi) w = fma(-la, lb, w);
-            if (bj == c + 1) f = publish_column(w, c + 1, bi, lane, k0, colb[c + 1], rsv, &bad_s);
-            if (c >= 1 && bi >= c) y = fma(-la_prev, Li[c - 1][bj], y);
-            if (bi == c) {                                        // row c of the inverse is final
-                const real x = y * rsv[c];
-                Li[c][bj] = x;
-                Lp[c * kNB + bj] = x;
-            }
-            la_prev = la;
-            __syncthreads();
-        }
-#ifdef VS_CHOL_TIMING
-        unsigned long long st2 = __builtin_readcyclecounter();
-#endif
-        if (bi < nb && bj <= bi) A[(int64_t)(k0 + bi) * ld + k0 + bj] = f;
-        if (rem <= 0) break;                                      // uniform: last panel
-        // 3. X <- X * Li^T
+        // 2. X <- X * Li^T
         {
             real b0[8], b1[8];
             load_frag(&Li[l15][0], lk, b0);
             load_frag(&Li[16 + l15][0], lk, b1);
-            for (int ti = wave; ti < nrt; ti += 16) {
+            for (int ti = wave; ti < nrt; ti += kCholWaves) {
                 real a[8];
                 load_frag(&X[16 * ti + l15][0], lk, a);
                 const d4 p0 = frag_product(a, b0), p1 = frag_product(a, b1);
@@ -682,48 +679,26 @@ chol_fused_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restri
         }
         __syncthreads();
 #ifdef VS_CHOL_TIMING
-        unsigned long long st3 = __builtin_readcyclecounter();
+        unsigned long long st2 = __builtin_readcyclecounter();
 #endif
-        // 4. trailing update.  Index arithmetic is kept off the issue path (tiles decoded
-        //    incrementally, one 64-bit address per tile, unconditional loads from rows clamped into
-        //    the window; the masks only guard the stores); the old values of a wave's next tile are
-        //    fetched before the product of the current one.
-        const int n_tiles = nrt * (nrt + 1) / 2;
-        {
-            const int ldi = (int)ld;
-            struct Tile { int ti, tj; real *p; real old[4]; };
-            int dec_a = 0, dec_tri = 0;
-            auto fetch = [&](int t, Tile &tl) {
-                while (t >= dec_tri + dec_a + 1) { dec_tri += dec_a + 1; dec_a++; }
-                tl.ti = dec_a;
-                tl.tj = t - dec_tri;
-                const int r0 = 16 * tl.ti + lk, r0c = min(r0, rem - 1);
-                tl.p = A + (int64_t)(base + r0c) * ld + base + 16 * tl.tj + l15;
-#pragma unroll
-                for (int v = 0; v < 4; v++)                                // rows beyond the window read its last row
-                    tl.old[v] = tl.p[(min(r0 + 4 * v, rem - 1) - r0c) * ldi];
-            };
-            Tile cur, nxt;
-            if (wave < n_tiles) fetch(wave, cur);
-            for (int t = wave; t < n_tiles; t += 16) {
-                if (t + 16 < n_tiles) fetch(t + 16, nxt);
-                real a[8], b[8];
-                load_frag(&X[16 * cur.ti + l15][0], lk, a);
-                load_frag(&X[16 * cur.tj + l15][0], lk, b);
-                const d4 p = frag_product(a, b);
-                const int cc = 16 * cur.tj + l15, r0 = 16 * cur.ti + lk;
-#pragma unroll
-                for (int v = 0; v < 4; v++) {                              // for stored rows the clamps are no-ops
-                    const int r = r0 + 4 * v;
-                    if (r < rem && cc <= r) cur.p[4 * v * ldi] = cur.old[v] - p[v];
-                }
-                cur = nxt;
-            }
-        }
+        // 3. tiles 0, 1, 2 = (0,0), (1,0), (1,1): the next diagonal block
+        if (wave < 3) update_lower_tiles(A, ld, X, base, rem, 0, wave, 1 << 20, lane);
         __syncthreads();
 #ifdef VS_CHOL_TIMING
+        unsigned long long st3 = __builtin_readcyclecounter();
+#endif
+        // 4. next block's factorisation | rest of the window update
+        if (wave == 0) factor_block(base, min(kNB, n - base));
+        else if (wave != 4)                                       // wave 4 shares wave 0's SIMD: its MFMAs
+            update_lower_tiles(A, ld, X, base, rem, 0, 3 + (wave < 4 ? wave - 1 : wave - 2), kCholWaves - 2, lane);   // would stretch the pivot chain
+#ifdef VS_CHOL_TIMING
         unsigned long long st4 = __builtin_readcyclecounter();
-        if (tid == 0 && k0 == 32 * 3) printf("panel: load %llu steps %llu product %llu trailing %llu rem %d\n", st1 - st0, st2 - st1, st3 - st2, st4 - st3, rem);
+#endif
+        __syncthreads();
+#ifdef VS_CHOL_TIMING
+        if ((tid == 0 || tid == 64) && k0 == 32 * 3)
+            printf("fused panel rem %d wave %d: load %llu product %llu block tiles %llu own phase 4 %llu, phase 4 with barrier %llu\n", rem,
+                   wave, st1 - st0, st2 - st1, st3 - st2, st4 - st3, (unsigned long long)__builtin_readcyclecounter() - st3);
 #endif
     }
     if (tid == 0 && bad_s && *info == 0) *info = bad_s;
@@ -1056,7 +1031,7 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
             hipLaunchKernelGGL(chol_window_kernel, dim3(1), dim3(kCholThreads), (size_t)2 * buf_rows * kXS * sizeof(real), s,
                                A, n, ld, bw, info, Linv, buf_rows);
         else
-            hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(1024), (size_t)buf_rows * kXS * sizeof(real), s,
+            hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(kCholThreads), (size_t)buf_rows * kXS * sizeof(real), s,
                                A, n, ld, bw, info, Linv);
         const int turns = (window + 127) / 128;
         if (turns <= 1) hipLaunchKernelGGL(chol_trsv_window_kernel<1>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);

@@ -195,6 +195,20 @@ def test_band_solver_matches_oracle_and_dense(orc, monkeypatch):
     assert abs(out1["final_cost"] - out0["final_cost"]) < 1e-7 * out0["final_cost"]
 
 
+def test_wide_band_solver_matches_oracle_and_dense(orc, monkeypatch):
+    """Half-bandwidth 305 of 720 unknowns: band storage with a trailing window wider than two LDS
+    panel images (the wide-window factorisation) and the 3-turn triangular solve."""
+    sc = synth.make_ba_scene(120, 2000, 4, band=50, seed=22)
+    ref, gpu = both(orc, sc)
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert rc == 0 and rel(d1, d0) < 1e-6 and rel(p1, p0) < 1e-6 and abs(m1 - m0) < 1e-8 * abs(m0)
+    monkeypatch.setenv("VS_BA_SOLVER", "dense")
+    d2, p2, m2 = gpu.lm_step(1e4)
+    assert rel(d2, d1) < 1e-8 and rel(p2, p1) < 1e-8
+    monkeypatch.delenv("VS_BA_SOLVER")
+
+
 def test_sharded_partial_systems_sum_to_the_whole():
     sc = synth.make_ba_config("c1", seed=10)
     d = np.full(6 * sc.Nc, 0.3), np.full(3 * sc.Np, 0.3)

@@ -68,7 +68,11 @@ __device__ __forceinline__ void project_obs(const CamData &c, const real *P, rea
     o.q[1] = c.R[3] * P[0] + c.R[4] * P[1] + c.R[5] * P[2];
     o.q[2] = c.R[6] * P[0] + c.R[7] * P[1] + c.R[8] * P[2];
     const real x = o.q[0] + c.t[0], y = o.q[1] + c.t[1], z = o.q[2] + c.t[2];
-    const real iy = real(1) / y;
+    // 1 / y from the hardware estimate and one cubically convergent step (4 instructions, within an
+    // ulp of the correctly rounded quotient) instead of the ~12-instruction IEEE division
+    const real y0 = __builtin_amdgcn_rcp(y);
+    const real ey = fma(-y, y0, real(1));
+    const real iy = fma(y0, fma(ey, ey, ey), y0);
     const real xi = x * iy, zi = z * iy;
     o.r0 = K.fx * xi + K.cx - u;
     o.r1 = -K.fy * zi + K.cy - v;

@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5shard"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5shard", "c5"])
     ap.add_argument("--no-extra", action="store_true", help="skip the matcher leg and larger BA shapes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--force-dist", action="store_true",
@@ -324,7 +324,7 @@ def main():
     if not args.no_extra:
         extra["matcher"] = bench_match(args, rank, world, dist, torch)
         if rank == 0 and world == 1:
-            for nm in ("c2", "c4", "c5shard"):
+            for nm in ("c2", "c4", "c5shard", "c5"):
                 extra[nm] = bench_ba_shape(nm, torch)
             extra["tracking"] = bench_tracking(torch)
     if rank == 0:

@@ -111,6 +111,7 @@ BA_CONFIGS = {
     "c2": (50, 20_000, 10, 50),
     "c4": (1_000, 500_000, 4, 16),
     "c5shard": (10_000, 500_000, 5, 32),
+    "c5": (10_000, 4_000_000, 5, 32),          # configs[4] whole, on one GPU
 }
 
 

@@ -96,6 +96,8 @@ struct vs_ba {
     DevBuf<CamData> cams;
     DevBuf<int> pt_ptr, lcam, lpt, lobs, cam_ptr, cpt, brow, bcol, bent;
     DevBuf<int> ditem_ptr, oitem_ptr;
+    DevBuf<int> lm_cam_lo;      // first camera seen by each landmark-kernel workgroup (range staging)
+    int lm_cam_span = 0;        // longest such range, 0 = range staging not used
     DevBuf<BlockItem> items, diag_items;
     DevBuf<unsigned char> cam_used, pt_used;
     DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
@@ -320,6 +322,25 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     h->n_lm_blocks = div_up(Np, kLmThreads);
     h->n_lm4_blocks = div_up(Np, kLmPerBlock);
     h->stage_cams = (size_t)Nc * (sizeof(CamData) + 6 * sizeof(real)) <= 48 * 1024;
+    // More cameras than fit LDS: when the cameras seen by the landmarks of one landmark-kernel
+    // workgroup span a short index range (keyframes in time order), that range is staged instead.
+    h->lm_cam_span = 0;
+    if (!h->stage_cams && getenv("VS_BA_NO_RANGE_STAGING") == nullptr) {
+        std::vector<int> lo((size_t)std::max(h->n_lm4_blocks, 1), 0);
+        int span = 1;
+        for (int w = 0; w < h->n_lm4_blocks; w++) {
+            const int j0 = w * kLmPerBlock, j1 = std::min(Np, j0 + kLmPerBlock);
+            int mn = Nc, mx = -1;
+            for (int p = pt_ptr[j0]; p < pt_ptr[j1]; p++) { mn = std::min(mn, lcam[p]); mx = std::max(mx, lcam[p]); }
+            if (mx < 0) { mn = 0; mx = 0; }
+            lo[w] = mn;
+            span = std::max(span, mx - mn + 1);
+        }
+        if ((size_t)span * sizeof(CamData) <= 32 * 1024) {
+            h->lm_cam_span = span;
+            VS_TRY(h->lm_cam_lo.upload(lo.data(), lo.size(), h->stream));
+        }
+    }
 
     hipStream_t s = h->stream;
     VS_TRY(h->pt_ptr.upload(pt_ptr.data(), pt_ptr.size(), s));
@@ -369,13 +390,19 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     mark(1);
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
-        hipLaunchKernelGGL(landmark_kernel<true>, dim3(h->n_lm4_blocks), dim3(kLmThreads), lds, h->stream,
+        hipLaunchKernelGGL(landmark_kernel<1>, dim3(h->n_lm4_blocks), dim3(kLmThreads), lds, h->stream,
                            h->Np, h->Nc, h->K, (const CamData *)nullptr, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p,
-                           h->hub, pd, h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
-    else
-        hipLaunchKernelGGL(landmark_kernel<false>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,
+                           h->hub, (const int *)nullptr, 0, pd, h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+    else if (h->lm_cam_span > 0)
+        hipLaunchKernelGGL(landmark_kernel<2>, dim3(h->n_lm4_blocks), dim3(kLmThreads),
+                           (size_t)h->lm_cam_span * sizeof(CamData), h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
-                           (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, pd,
+                           (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->lm_cam_lo.p,
+                           h->lm_cam_span, pd, h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+    else
+        hipLaunchKernelGGL(landmark_kernel<0>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,
+                           h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
+                           (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, (const int *)nullptr, 0, pd,
                            h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
     VS_TRY(launch_check("landmark_kernel"));
     mark(2);

@@ -61,6 +61,15 @@ struct ObsLin {
     real q[3];               // R * Pw
 };
 
+// 1 / d from the hardware estimate and one cubically convergent step (4 instructions, within an
+// ulp of the correctly rounded quotient) instead of the ~12-instruction IEEE division.
+__device__ __forceinline__ real fast_rcp(real d)
+{
+    const real y0 = __builtin_amdgcn_rcp(d);
+    const real e = fma(-d, y0, real(1));
+    return fma(y0, fma(e, e, e), y0);
+}
+
 __device__ __forceinline__ void project_obs(const CamData &c, const real *P, real u, real v,
                                             const Intr &K, ObsLin &o)
 {
@@ -68,11 +77,7 @@ __device__ __forceinline__ void project_obs(const CamData &c, const real *P, rea
     o.q[1] = c.R[3] * P[0] + c.R[4] * P[1] + c.R[5] * P[2];
     o.q[2] = c.R[6] * P[0] + c.R[7] * P[1] + c.R[8] * P[2];
     const real x = o.q[0] + c.t[0], y = o.q[1] + c.t[1], z = o.q[2] + c.t[2];
-    // 1 / y from the hardware estimate and one cubically convergent step (4 instructions, within an
-    // ulp of the correctly rounded quotient) instead of the ~12-instruction IEEE division
-    const real y0 = __builtin_amdgcn_rcp(y);
-    const real ey = fma(-y, y0, real(1));
-    const real iy = fma(y0, fma(ey, ey, ey), y0);
+    const real iy = fast_rcp(y);
     const real xi = x * iy, zi = z * iy;
     o.r0 = K.fx * xi + K.cx - u;
     o.r1 = -K.fy * zi + K.cy - v;
@@ -233,18 +238,20 @@ constexpr int kLmPerBlock = kLmThreads / kLpl;        // landmarks per workgroup
 
 // (a)+(b), landmark side.  Four lanes per landmark j share its observations:
 // V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
-// Cameras come from LDS when they fit (STAGE_CAMS).  With prep_t / prep_rpy given (STAGE_CAMS only)
+// Cameras come from LDS when they all fit (STAGE 1), or when the cameras seen by the landmarks of
+// one workgroup span a short index range (STAGE 2, cam_lo[workgroup] = first camera of the range,
+// cam_span = longest range: keyframes in time order).  With prep_t / prep_rpy given (STAGE 1 only)
 // every workgroup builds the camera records itself, straight into LDS (which then also holds
 // 6 Nc reals of sines and cosines behind the records), and workgroup 0 also stores them to
 // `cams_out` for the kernels that follow: no separate camera pass.
-template <bool STAGE_CAMS>
+template <int STAGE>   // 0: cameras gathered from global memory, 1: all cameras in LDS, 2: this workgroup's camera range in LDS
 __global__ void __launch_bounds__(kLmThreads)
 landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                 const real *__restrict__ prep_t, const real *__restrict__ prep_rpy,
                 CamData *__restrict__ cams_out,
                 const real *__restrict__ pts, const int *__restrict__ pt_ptr,
                 const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
-                PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
+                const int *__restrict__ cam_lo, int cam_span, PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
                 real *__restrict__ hub_w, real *__restrict__ cost_partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -259,7 +266,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
         b = pt_ptr[j]; e = pt_ptr[j + 1];
         P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
     }
-    if (STAGE_CAMS) {
+    if (STAGE == 1) {
         if (prep_t) {
             // one sincos per thread (3 Nc of them) instead of three per camera in a single wave
             real *sc = reinterpret_cast<real *>(scams + Nc);
@@ -278,6 +285,15 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
         }
         __syncthreads();
     }
+    int lo = 0;
+    if (STAGE == 2) {
+        lo = cam_lo[blockIdx.x];
+        const int cnt = min(cam_span, Nc - lo);
+        const double2 *src = reinterpret_cast<const double2 *>(cams + lo);
+        double2 *dst = reinterpret_cast<double2 *>(scams);
+        for (int i = threadIdx.x; i < cnt * 8; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     real acc[10];                                      // V (6), g (3), cost
 #pragma unroll
     for (int v = 0; v < 10; v++) acc[v] = real(0);
@@ -294,7 +310,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                 uv_next = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(pos + kLpl));
             }
             CamData cd;
-            if (STAGE_CAMS) cd = scams[c]; else load_cam(cams, c, cd);
+            if (STAGE == 0) load_cam(cams, c, cd); else cd = scams[c - lo];
             ObsLin o;
             project_obs(cd, P, uv.x, uv.y, K, o);
             real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
@@ -342,13 +358,13 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                     real x = s2 * d[k];
                     x = x < damp.min_d ? damp.min_d : x;
                     x = x > damp.max_d ? damp.max_d : x;
-                    l[k] = x / damp.radius / s2;
+                    l[k] = x * fast_rcp(damp.radius * s2);
                 }
                 l0 = l[0]; l1 = l[1]; l2 = l[2];
             }
             const real a = V[0] + l0, bb = V[1], cc = V[2], d = V[3] + l1, ee = V[4], f = V[5] + l2;
             const real c00 = d * f - ee * ee, c01 = cc * ee - bb * f, c02 = bb * ee - cc * d;
-            const real id = real(1) / (a * c00 + bb * c01 + cc * c02);
+            const real id = fast_rcp(a * c00 + bb * c01 + cc * c02);
             vi[0] = c00 * id; vi[1] = c01 * id; vi[2] = c02 * id;
             vi[3] = (a * f - cc * cc) * id; vi[4] = (bb * cc - a * ee) * id;
             vi[5] = (a * d - bb * bb) * id;

@@ -315,10 +315,23 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL and gloo print banners on stdout when the communicator comes up: keep stdout for
+        # the one JSON line by pointing file descriptor 1 at stderr until the first collective is done
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            warm = torch.zeros(8, device="cuda", dtype=torch.float64)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     ba = bench_ba(args, rank, world, dist, torch)
     extra = {}
     if not args.no_extra:

@@ -105,6 +105,21 @@ def test_unstaged_cameras_path(orc):
     assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10
 
 
+def test_camera_range_staging_path(orc):
+    """Landmark ids in keyframe order: each landmark-kernel workgroup sees a short camera range and
+    stages it in LDS (600 cameras do not fit as a whole)."""
+    sc = synth.landmarks_in_keyframe_order(synth.make_ba_scene(600, 3000, 4, band=16, seed=14))
+    ref, gpu = both(orc, sc)
+    dc = np.full(6 * sc.Nc, 0.5); dp = np.full(3 * sc.Np, 0.5)
+    s = ref.schur(dc=dc, dp=dp)
+    gpu.linearize(dc, dp)
+    S, rhs, _ = dense_from(gpu)
+    assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert rc == 0 and rel(d1, d0) < 1e-6 and rel(p1, p0) < 1e-6
+
+
 def test_linearize_is_bitwise_reproducible():
     sc = synth.make_ba_config("c1", seed=2)
     gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)

@@ -105,6 +105,20 @@ def make_ba_scene(Nc, Np, k_mean, band=None, seed=0, k_jitter=2, cam_step=0.05, 
                    pts_gt=pts_gt, K=np.array([FX, FY, CX, CY]))
 
 
+def landmarks_in_keyframe_order(sc):
+    """The same scene with the landmarks renumbered by the first camera that sees them (the order
+    in which the reference creates tracked points); observations stay landmark-major."""
+    first = np.full(sc.Np, np.iinfo(np.int64).max)
+    np.minimum.at(first, sc.pt, sc.cam)
+    order = np.argsort(first, kind="stable")                 # new id -> old id
+    rank = np.empty_like(order)
+    rank[order] = np.arange(sc.Np)
+    pt = rank[sc.pt]
+    o = np.lexsort((sc.cam, pt))
+    return BAScene(cam=sc.cam[o], pt=pt[o].astype(np.int32), uv=sc.uv[o], t0=sc.t0, rpy0=sc.rpy0,
+                   pts0=sc.pts0[order], t_gt=sc.t_gt, rpy_gt=sc.rpy_gt, pts_gt=sc.pts_gt[order], K=sc.K)
+
+
 BA_CONFIGS = {
     # name: (Nc, Np, k_mean, band)   -- BASELINE.json configs[1], [3], one 1/8 shard of [4]
     "c1": (10, 500, 6, 10),

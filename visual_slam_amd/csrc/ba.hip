@@ -98,6 +98,7 @@ struct vs_ba {
     DevBuf<int> ditem_ptr, oitem_ptr;
     DevBuf<int> lm_cam_lo;      // first camera seen by each landmark-kernel workgroup (range staging)
     int lm_cam_span = 0;        // longest such range, 0 = range staging not used
+    int n_multi_diag = 0, n_multi_off = 0;
     DevBuf<BlockItem> items, diag_items;
     DevBuf<unsigned char> cam_used, pt_used;
     DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
@@ -269,7 +270,11 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     if (const char *e = getenv("VS_BA_ITEM_WAVES")) h->item_waves = atoi(e) == 4 ? 4 : 1;   // tuning knobs
     int ept = h->item_waves == 4 ? kEpt4 : kEpt1;          // entries per thread and item
     if (const char *e = getenv("VS_BA_ITEM_EPT")) ept = std::min(ept, std::max(1, atoi(e)));
-    const int ch = h->item_waves * kWave * ept;
+    // a 4-wave item holds up to max_chunks chunks of entries (the block kernel walks them in a loop
+    // with the sums in registers): fewer partials, and at 50 cameras every block is one item
+    const int chunk = h->item_waves * kWave * ept;
+    const int max_chunks = h->item_waves == 4 ? 6 : 1;
+    const int ch = chunk * max_chunks;
     // Items are listed block row by block row (camera c's diagonal item(s), then its
     // off-diagonal blocks (c, c') in column order) so that a contiguous range of items is a band
     // of cameras.  With fixed points only the diagonal items are launched (diag_items).
@@ -319,6 +324,9 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     }
     h->n_diag_items = n_diag_items;
     h->n_off_items = n_off_items;
+    h->n_multi_diag = h->n_multi_off = 0;          // blocks that are not exactly one item: finalize sums (or zeroes) them
+    for (int c = 0; c < Nc; c++) h->n_multi_diag += di_ptr[c + 1] - di_ptr[c] != 1;   // empty blocks too:
+    for (int k = 0; k < nb_off; k++) h->n_multi_off += oi_ptr[k + 1] - oi_ptr[k] != 1; // finalize zeroes them
     h->n_lm_blocks = div_up(Np, kLmThreads);
     h->n_lm4_blocks = div_up(Np, kLmPerBlock);
     h->stage_cams = (size_t)Nc * (sizeof(CamData) + 6 * sizeof(real)) <= 48 * 1024;
@@ -415,12 +423,12 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                 hipLaunchKernelGGL((blocks_kernel<4, kEpt4>), dim3(n_items), dim3(4 * kWave), 0, h->stream, n_items, list,
                                    h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
-                                   h->Nc, h->nb_off);
+                                   h->Nc, h->nb_off, h->cost_partial.p, h->n_lm4_blocks);
             else
                 hipLaunchKernelGGL((blocks_kernel<1, kEpt1>), dim3(n_items), dim3(kWave), 0, h->stream, n_items, list,
                                    h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
-                                   h->Nc, h->nb_off);
+                                   h->Nc, h->nb_off, h->cost_partial.p, h->n_lm4_blocks);
             VS_TRY(launch_check("blocks_kernel"));
         }
     }
@@ -429,11 +437,18 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     const int nb_fin = h->fix_points ? 0 : h->nb_off;
     if (h->fix_points && h->nb_off > 0)
         VS_HIP(hipMemsetAsync(h->S_off(), 0, (size_t)h->nb_off * 36 * sizeof(real), h->stream));
-    const int64_t n_fin = (int64_t)h->Nc * kDiagVals + (int64_t)nb_fin * kOffVals;
-    hipLaunchKernelGGL(finalize_kernel, dim3(div_up(n_fin, 256) + 1), dim3(256), 0, h->stream, h->Nc, h->nb_off, nb_fin,
-                       h->ditem_ptr.p, h->diag_partial.p, h->oitem_ptr.p, h->off_partial.p, h->n_lm4_blocks,
-                       h->cost_partial.p, h->red.p);
-    VS_TRY(launch_check("finalize_kernel"));
+    // The block kernel has written every block that is exactly one item, and the cost.  The
+    // finalize pass is needed for blocks of several items (partials) or none (zero), and for the
+    // cost when no item ran at all.
+    const int n_items_run = h->n_diag_items + (h->fix_points ? 0 : h->n_off_items);
+    const bool need_fin = h->n_multi_diag > 0 || (!h->fix_points && h->n_multi_off > 0) || n_items_run == 0;
+    if (need_fin) {
+        const int64_t n_fin = (int64_t)h->Nc * kDiagVals + (int64_t)nb_fin * kOffVals;
+        hipLaunchKernelGGL(finalize_kernel, dim3(div_up(n_fin, 256) + 1), dim3(256), 0, h->stream, h->Nc, h->nb_off, nb_fin,
+                           h->ditem_ptr.p, h->diag_partial.p, h->oitem_ptr.p, h->off_partial.p,
+                           n_items_run == 0 ? h->n_lm4_blocks : -1, h->cost_partial.p, h->red.p);
+        VS_TRY(launch_check("finalize_kernel"));
+    }
     mark(5);
     h->linearized = true;
     return VS_OK;

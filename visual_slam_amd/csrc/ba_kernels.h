@@ -559,7 +559,8 @@ __device__ __forceinline__ void load_rec(const real *__restrict__ lmrec, int j, 
         if (i < n2) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
 }
 
-// (a)+(b), block side: one workgroup of WAVES waves per work item of at most EPT entries per thread.
+// (a)+(b), block side: one workgroup of WAVES waves per work item, walked in chunks of EPT entries
+// per thread.  Workgroup 0 also adds up the landmark kernel's cost partials.
 //   diagonal items (ca == cb): a slice of one camera's observations (camera-major view).  Per
 //     observation, with N = I - Jp Vinv Jp^T (2x2; N = I when points are fixed):
 //       S_cc += Jc^T N Jc,  rhs += Jc^T (Jp Vinv g_p - r),  diag(U) += diag(Jc^T Jc),  g_c += Jc^T r
@@ -577,7 +578,7 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
               const int *__restrict__ cpt, const real *__restrict__ cuv,
               const int *__restrict__ bent, HuberObs hub, const real *__restrict__ hub_w,
               int fix_points, real *__restrict__ diag_partial, real *__restrict__ off_partial,
-              real *red, int Nc, int nb_off)
+              real *red, int Nc, int nb_off, const real *__restrict__ cost_partial, int n_cost_partials)
 {
     __shared__ real lds[WAVES * 21 * kRedStride + WAVES * 24];
     const int lane = threadIdx.x & 63;
@@ -595,17 +596,41 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
     }
     const BlockItem it = items[item];
     const RedView rv = red_view(red, Nc, nb_off);
-    constexpr int kStride = WAVES * kWave;
-    const int k0 = it.begin + (int)threadIdx.x;
-    if (it.ca == it.cb) {
-        int jx[EPT];
+    if (blockIdx.x == 0) {
+        // total cost = fixed-order sum of the landmark kernel's per-workgroup partials
+        real c = real(0);
+        for (int i = threadIdx.x; i < n_cost_partials; i += WAVES * kWave) c += cost_partial[i];
 #pragma unroll
-        for (int e = 0; e < EPT; e++) jx[e] = k0 + e * kStride < it.end ? cpt[k0 + e * kStride] : -1;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+        if (WAVES > 1) {
+            if (lane == 0) xw[wave] = c;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                c = xw[0];
+#pragma unroll
+                for (int w = 1; w < WAVES; w++) c += xw[w];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *rv.cost = c;
+    }
+    constexpr int kStride = WAVES * kWave;
+    // a 4-wave item is walked in chunks of EPT entries per thread, the sums stay in registers across
+    // chunks; a 1-wave item is one chunk (the loop costs that form registers it does not have)
+    constexpr int kChunk = kStride * EPT;
+    constexpr bool kLoop = WAVES > 1;
+    if (it.ca == it.cb) {
         real acc[kDiagVals];
 #pragma unroll
         for (int v = 0; v < kDiagVals; v++) acc[v] = real(0);
         CamData cd;
         load_cam(cams, it.ca, cd);
+        int cb0 = it.begin;
+        do {
+        const int k0 = cb0 + (int)threadIdx.x;
+        int jx[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) jx[e] = k0 + e * kStride < it.end ? cpt[k0 + e * kStride] : -1;
         real rec[2][kRec], uv[2][2];
         auto fetch = [&](int e, int buf) {
             if (jx[e] >= 0) {
@@ -664,6 +689,8 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
                 acc[21 + p] = t1; acc[27 + p] = t2; acc[33 + p] = t3;
             }
         }
+        cb0 += kChunk;
+        } while (kLoop && cb0 < it.end);   // chunks
         const real s1 = group_reduce<21, WAVES>(acc, lds_wave, xw, lane, wave);
         const real s2 = group_reduce<18, WAVES>(acc + 21, lds_wave, xw, lane, wave);
         if (wave == 0) {
@@ -676,15 +703,18 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
             }
         }
     } else {
-        int jx[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; e++) jx[e] = k0 + e * kStride < it.end ? bent[k0 + e * kStride] : -1;
         real acc[kOffVals];
 #pragma unroll
         for (int v = 0; v < kOffVals; v++) acc[v] = real(0);
         CamData A, B;
         load_cam(cams, it.ca, A);
         load_cam(cams, it.cb, B);
+        int cb0 = it.begin;
+        do {
+        const int k0 = cb0 + (int)threadIdx.x;
+        int jx[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) jx[e] = k0 + e * kStride < it.end ? bent[k0 + e * kStride] : -1;
         real rec[2][10];
         if (jx[0] >= 0) load_rec(lmrec, jx[0], rec[0], 5);
 #pragma unroll
@@ -733,6 +763,8 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
                     acc[6 * p + q] = t;
                 }
         }
+        cb0 += kChunk;
+        } while (kLoop && cb0 < it.end);   // chunks
         const real s1 = group_reduce<18, WAVES>(acc, lds_wave, xw, lane, wave);
         const real s2 = group_reduce<18, WAVES>(acc + 18, lds_wave, xw, lane, wave);
         if (wave == 0 && lane < 18) {
@@ -779,7 +811,8 @@ finalize_kernel(int Nc, int nb_off, int nb_sum, const int *__restrict__ diag_ite
 {
     __shared__ real scratch[4];
     const RedView rv = red_view(red, Nc, nb_off);
-    if (blockIdx.x == gridDim.x - 1) {                 // last workgroup: cost
+    if (blockIdx.x == gridDim.x - 1) {                 // last workgroup: cost (when asked to)
+        if (n_cost_partials < 0) return;
         real s = real(0);
         for (int i = threadIdx.x; i < n_cost_partials; i += 256) s += cost_partial[i];
         s = block_sum_256(s, scratch);

@@ -273,7 +273,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     // a 4-wave item holds up to max_chunks chunks of entries (the block kernel walks them in a loop
     // with the sums in registers): fewer partials, and at 50 cameras every block is one item
     const int chunk = h->item_waves * kWave * ept;
-    const int max_chunks = h->item_waves == 4 ? 6 : 1;
+    const int max_chunks = h->item_waves == 4 ? 24 / kEpt4 : 1;   // 6144 entries per 4-wave item
     const int ch = chunk * max_chunks;
     // Items are listed block row by block row (camera c's diagonal item(s), then its
     // off-diagonal blocks (c, c') in column order) so that a contiguous range of items is a band

@@ -233,10 +233,13 @@ struct HuberObs {
 // Per-landmark record written by the landmark kernel and read by the block and
 // back-substitution kernels: P[3], inverse of the damped V (xx,xy,xz,yy,yz,zz), g_p[3].
 constexpr int kRec = 12;
-constexpr int kLpl = 4;                               // lanes cooperating on one landmark
+#ifndef VS_LPL
+#define VS_LPL 2
+#endif
+constexpr int kLpl = VS_LPL;                          // lanes cooperating on one landmark (power of two)
 constexpr int kLmPerBlock = kLmThreads / kLpl;        // landmarks per workgroup
 
-// (a)+(b), landmark side.  Four lanes per landmark j share its observations:
+// (a)+(b), landmark side.  kLpl lanes per landmark j share its observations:
 // V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
 // Cameras come from LDS when they all fit (STAGE 1), or when the cameras seen by the landmarks of
 // one workgroup span a short index range (STAGE 2, cam_lo[workgroup] = first camera of the range,
@@ -258,7 +261,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
     CamData *scams = reinterpret_cast<CamData *>(smem_raw);
     __shared__ real red[4];
     // the landmark's own data first: these loads are in flight while the cameras are staged
-    const int j = blockIdx.x * kLmPerBlock + ((int)threadIdx.x >> 2);
+    const int j = blockIdx.x * kLmPerBlock + (int)threadIdx.x / kLpl;
     const int sl = threadIdx.x & (kLpl - 1);
     real P[3] = { 0, 0, 0 };
     int b = 0, e = 0;
@@ -333,12 +336,11 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
             acc[8] = fma(Jp[2], o.r0, fma(Jp[5], o.r1, acc[8]));
         }
     }
-    // fixed-order sum over the 4 cooperating lanes (every lane ends with the same totals)
+    // fixed-order sum over the cooperating lanes (every lane ends with the same totals)
 #pragma unroll
-    for (int v = 0; v < 10; v++) {
-        acc[v] += __shfl_xor(acc[v], 1, 64);
-        acc[v] += __shfl_xor(acc[v], 2, 64);
-    }
+    for (int v = 0; v < 10; v++)
+#pragma unroll
+        for (int off = 1; off < kLpl; off <<= 1) acc[v] += __shfl_xor(acc[v], off, 64);
     real cost = real(0);
     if (j < Np && sl == 0) {
         cost = acc[9];

@@ -108,8 +108,10 @@ def bench_ba(args, rank, world, dist, torch):
         traffic, traffic_src = committed_traffic(args.workload) if world == 1 else (None, None)
         out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                                frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                               kernel="fused linearise pipeline: prep_cameras + landmark + blocks + finalize kernels "
-                                      "(HIP-event intervals, each carrying ~5 us of event overhead)",
+                               kernel="fused linearise pipeline: landmark + blocks kernels (plus prep_cameras when the "
+                                      "cameras do not fit LDS and finalize when a block spans several work items; at "
+                                      "50 cameras those two intervals are empty). HIP-event intervals, each carrying "
+                                      "~5 us of event overhead, so the sum is longer than the timed step",
                                dominant_kernel=dom, kernels_ms=k_ms, pipeline_ms=float(ms[5]),
                                algorithmic_bytes=int(alg))
     ba.close()

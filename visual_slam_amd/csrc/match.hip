@@ -125,6 +125,12 @@ __device__ __forceinline__ float vmed3(float a, float b, float c)
     asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // union of two (best, second) pairs of packed scores
 __device__ __forceinline__ void top2_union(float &b1, float &b2, float ob1, float ob2)
@@ -360,13 +366,24 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
     // running top-2 on PACKED scores: the low 6 mantissa bits of each score carry the element's
     // position inside the wave's 64 rows / columns (relative perturbation <= 2^-17, part of the
     // band), so no index needs tracking:
-    //   b2 <- median(b1, b2, key);  b1 <- max(b1, key)         (2 VALU + 1 pack per element)
+    //   b2 <- median(b1, b2, key);  b1 <- max(b1, key)         (2 VALU + 1 pack per element;
+    //   the two-key form below needs 1.5 VALU + 1 pack per element)
     // Each lane packs a 5-bit position; bit 5 (= lane half) is set once on the lane's best.
 #define VS_TOP2_STEP(v, e)                                                                  \
     do {                                                                                     \
         const float k_ = __uint_as_float((__float_as_uint(v) & 0xffffffc0u) | (unsigned)(e)); \
         b2 = vmed3(b1, b2, k_);                                                              \
         b1 = vmax(b1, k_);                                                                   \
+    } while (0)
+    // two keys at once (b1 >= b2 holds before and after): the largest of {b1, k1, k2} is the new
+    // best, and since b2 <= b1 the new second is max(b2, median(b1, k1, k2)): 3 VALU for 2 keys
+#define VS_TOP2_STEP2(v1, e1, v2, e2)                                                        \
+    do {                                                                                     \
+        const float k1_ = __uint_as_float((__float_as_uint(v1) & 0xffffffc0u) | (unsigned)(e1)); \
+        const float k2_ = __uint_as_float((__float_as_uint(v2) & 0xffffffc0u) | (unsigned)(e2)); \
+        const float t_ = vmed3(b1, k1_, k2_);                                                \
+        b1 = vmax3(b1, k1_, k2_);                                                            \
+        b2 = vmax(b2, t_);                                                                   \
     } while (0)
     const unsigned half_bit = (unsigned)half << 5;
     // columns: top-2 over the wave's 64 rows; position code e = 32*half + 16*m + r stands for
@@ -377,7 +394,7 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) VS_TOP2_STEP(acc[m][n][r], m * 16 + r);
+            for (int r = 0; r < 16; r += 2) VS_TOP2_STEP2(acc[m][n][r], m * 16 + r, acc[m][n][r + 1], m * 16 + r + 1);
         b1 = __uint_as_float(__float_as_uint(b1) | half_bit);
         top2_union(b1, b2, __shfl_xor(b1, 32, 64), __shfl_xor(b2, 32, 64));
         if (half == 0) {
@@ -402,8 +419,8 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const float4 q = rowp[c];
-            VS_TOP2_STEP(q.x, 4 * c); VS_TOP2_STEP(q.y, 4 * c + 1);
-            VS_TOP2_STEP(q.z, 4 * c + 2); VS_TOP2_STEP(q.w, 4 * c + 3);
+            VS_TOP2_STEP2(q.x, 4 * c, q.y, 4 * c + 1);
+            VS_TOP2_STEP2(q.z, 4 * c + 2, q.w, 4 * c + 3);
         }
         b1 = __uint_as_float(__float_as_uint(b1) | half_bit);
         top2_union(b1, b2, __shfl_xor(b1, 32, 64), __shfl_xor(b2, 32, 64));
@@ -420,6 +437,7 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         for (int i = 0; i < 64; i++) g_match_stamps[wave * 64 + i] = i < n_stamp ? s_stamps[wave * 64 + i] : 0ull;
 #endif
 #undef VS_TOP2_STEP
+#undef VS_TOP2_STEP2
 #undef VS_ISSUE_STAGE
 }
 

@@ -234,6 +234,27 @@ def bench_match(args, rank, world, dist, torch, n=4096, total_pairs=64):
         out["library_gemm_fp16"] = dict(ms_per_batch=lib_ms, tflops=flops / (lib_ms * 1e-3) / 1e12,
                                         note="torch.bmm fp16 (hipBLASLt) of the same contraction, scores "
                                              "materialised, no top-2: a ceiling reference, not a matcher")
+        if world == 1:
+            # throughput with two batches in flight: a second handle on a second stream, batches
+            # alternate, so one batch's merge / rescan / compaction kernels run beside the next
+            # batch's score kernel.  Reported beside the one-stream number, not instead of it.
+            s2 = torch.cuda.Stream()
+            mt2 = vm.Matcher(pairs, n, n)
+            mt2.set_stream(s2.cuda_stream)
+            for p, (d0, d1) in enumerate(keep):
+                mt2.set_pair(p, (d0.data_ptr(), n), (d1.data_ptr(), n))
+            both = (mt, mt2)
+            for it in range(4):
+                both[it % 2].run(pairs, 0.7)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for it in range(2 * steps):
+                both[it % 2].run(pairs, 0.7)
+            torch.cuda.synchronize()
+            per2 = (time.perf_counter() - t3) / (2 * steps)
+            out["two_streams"] = dict(ms_per_batch=per2 * 1e3, query_rows_per_s=pairs * n / per2,
+                                      note="two handles on two streams, batches alternating")
+            mt2.close()
     mt.close()
     return out
 

@@ -114,6 +114,27 @@ def bench_ba(args, rank, world, dist, torch):
                                       "~5 us of event overhead, so the sum is longer than the timed step",
                                dominant_kernel=dom, kernels_ms=k_ms, pipeline_ms=float(ms[5]),
                                algorithmic_bytes=int(alg))
+    if rank == 0 and world == 1 and not args.no_extra:
+        # throughput with two independent problems in flight (a second handle on a second stream,
+        # steps alternating): one problem's landmark kernel runs beside the other's block kernel.
+        # Reported beside the headline, which stays one problem on one stream (an LM loop is serial).
+        s2 = torch.cuda.Stream()
+        sc2, ba2 = make_problem(args.workload, rank, world)
+        ba2.set_stream(s2.cuda_stream)
+        pair = ((ba, pc, pp), (ba2, pc, pp))
+        for it in range(2 * args.warmup):
+            b_, c_, p_ = pair[it % 2]
+            assert lib.vs_ba_linearize(b_.h, c_, p_) == 0
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for it in range(2 * args.steps):
+            b_, c_, p_ = pair[it % 2]
+            lib.vs_ba_linearize(b_.h, c_, p_)
+        torch.cuda.synchronize()
+        per2 = (time.perf_counter() - t2) / (2 * args.steps)
+        out["two_streams"] = dict(ms_per_step=per2 * 1e3, obs_per_s=sc.No / per2,
+                                  note="two problems of this workload on two streams, steps alternating")
+        ba2.close()
     ba.close()
     return out
 
@@ -375,6 +396,8 @@ def main():
                 "precision": "fp64 values, int32 indices"},
             "roofline": ba["roofline"],
         }
+        if "two_streams" in ba:
+            extra["ba_two_streams"] = ba["two_streams"]
         if "matcher" in extra:   # second half of the metric: SuperPoint query rows matched per second
             line["matcher_value"] = extra["matcher"]["query_rows_per_s"]
             line["matcher_unit"] = "query rows/s (64 pairs of 4096 x 4096, mutual check)"

@@ -499,9 +499,9 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
     VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
     VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
     hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * Nc, 256)), dim3(256), 0, s, Nc, h->udiag(),
-                       h->scale_c.p, (const real *)nullptr, (real)radius, (real)min_d, (real)max_d, h->lam_c.p, h->S_diag());
+                       h->scale_c.p, (const real *)nullptr, (real)radius, (real)min_d, (real)max_d, h->lam_c.p, h->S_diag(),
+                       h->rhs(), h->dcam.p, h->info.p);
     VS_TRY(launch_check("camera_damping_kernel"));
-    VS_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), s));
     if (h->fix_points || h->nb_off == 0) {
         hipLaunchKernelGGL(solve6_kernel, dim3(div_up(Nc, 64)), dim3(64), 0, s, Nc, h->S_diag(), h->rhs(), h->dcam.p, h->info.p);
         VS_TRY(launch_check("solve6_kernel"));
@@ -528,7 +528,6 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         hipLaunchKernelGGL(assemble_lower_kernel, dim3(div_up(ne, 256)), dim3(256), 0, s, Nc, h->nb_off,
                            h->brow.p, h->bcol.p, h->S_diag(), h->S_off(), A, ld);
         VS_TRY(launch_check("assemble_lower_kernel"));
-        VS_HIP(hipMemcpyAsync(h->dcam.p, h->rhs(), (size_t)n * sizeof(real), hipMemcpyDeviceToDevice, s));
         const size_t linv_elems = (size_t)div_up(n, kNB) * kNB * kNB;
         if (h->linv.n < linv_elems) VS_TRY(h->linv.alloc(linv_elems));
         VS_TRY(cholesky_solve(A, h->dcam.p, n, ld, bw, h->info.p, h->linv.p, s));
@@ -543,7 +542,6 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
                            h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p,
                            (int)h->fix_points, h->lmrec.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
     VS_TRY(launch_check("backsub_kernel"));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->mcc_partial.p, h->scalars.p);
     const int64_t npar = 6 * (int64_t)Nc + 3 * (int64_t)Np;
     const int ncb = div_up(npar, 256);
     if (h->cand_partial.n < (size_t)ncb * 2) VS_TRY(h->cand_partial.alloc((size_t)ncb * 2 + 2));
@@ -560,19 +558,18 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
             hipLaunchKernelGGL(cost_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, Np, Nc, h->K,
                                h->cams.p, h->pts2.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
         VS_TRY(launch_check("cost_kernel"));
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->cost_partial.p, h->scalars.p + 3);
     }
-    // |x|^2 and |d|^2: sums of the interleaved per-block partials, on the device
-    hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(256), 0, s, ncb, h->cand_partial.p, h->scalars.p + 1);
-    VS_TRY(launch_check("sum_pairs_kernel"));
-    real host4[4] = { 0, 0, 0, 0 };
+    // model cost change, |x|^2, |d|^2, candidate cost and the solver status: one launch, one copy
+    hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->mcc_partial.p, ncb,
+                       h->cand_partial.p, want_candidate_cost ? h->n_lm_blocks : 0, h->cost_partial.p, h->info.p,
+                       h->scalars.p);
+    VS_TRY(launch_check("step_scalars_kernel"));
+    real host8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     VS_TRY(cross_gpu_sum(h, h->scalars.p, 4));
-    VS_HIP(hipMemcpyAsync(host4, h->scalars.p, 4 * sizeof(real), hipMemcpyDeviceToHost, s));
-    int info = 0;
-    VS_HIP(hipMemcpyAsync(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipMemcpyAsync(host8, h->scalars.p, 8 * sizeof(real), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
-    sc->mcc = host4[0]; sc->xnorm2 = host4[1]; sc->snorm2 = host4[2]; sc->cost_new = host4[3];
-    *numeric_fail = info != 0;
+    sc->mcc = host8[0]; sc->xnorm2 = host8[1]; sc->snorm2 = host8[2]; sc->cost_new = host8[3];
+    *numeric_fail = host8[6] != 0.0;
     return VS_OK;
 }
 
@@ -759,7 +756,8 @@ int vs_ba_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p)
     VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
     if (lc) {
         hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * h->Nc, 256)), dim3(256), 0, s, h->Nc, h->udiag(),
-                           (const real *)nullptr, lc, real(1), real(0), real(0), (real *)nullptr, h->S_diag());
+                           (const real *)nullptr, lc, real(1), real(0), real(0), (real *)nullptr, h->S_diag(),
+                           (const real *)nullptr, (real *)nullptr, (int *)nullptr);
         VS_TRY(launch_check("camera_damping_kernel"));
     }
     return VS_OK;

@@ -848,16 +848,29 @@ sum_partials_kernel(int n, const real *__restrict__ in, real *__restrict__ out)
     if (threadIdx.x == 0) *out = s;
 }
 
-// Sums of `n` interleaved pairs (a_i, b_i) -> out[0], out[1] (single block, fixed order).
+// The scalars of one LM step in one launch (single block, fixed order): out[0] = sum of the model
+// cost change partials, out[1], out[2] = sums of the interleaved (|x|^2, |d|^2) partials, out[3] =
+// sum of the candidate cost partials (when n_cost > 0), out[6] = the solver's status word.
 __global__ void __launch_bounds__(256)
-sum_pairs_kernel(int n, const real *__restrict__ in, real *__restrict__ out)
+step_scalars_kernel(int n_mcc, const real *__restrict__ mcc_partial, int n_pairs,
+                    const real *__restrict__ pair_partial, int n_cost,
+                    const real *__restrict__ cost_partial, const int *__restrict__ info,
+                    real *__restrict__ out)
 {
     __shared__ real red[4];
-    real a = real(0), b = real(0);
-    for (int i = threadIdx.x; i < n; i += 256) { a += in[2 * (int64_t)i]; b += in[2 * (int64_t)i + 1]; }
+    real m = real(0), a = real(0), b = real(0), c = real(0);
+    for (int i = threadIdx.x; i < n_mcc; i += 256) m += mcc_partial[i];
+    for (int i = threadIdx.x; i < n_pairs; i += 256) { a += pair_partial[2 * (int64_t)i]; b += pair_partial[2 * (int64_t)i + 1]; }
+    for (int i = threadIdx.x; i < n_cost; i += 256) c += cost_partial[i];
+    m = block_sum_256(m, red);
     a = block_sum_256(a, red);
     b = block_sum_256(b, red);
-    if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+    c = block_sum_256(c, red);
+    if (threadIdx.x == 0) {
+        out[0] = m; out[1] = a; out[2] = b;
+        if (n_cost > 0) out[3] = c;
+        out[6] = (real)*info;
+    }
 }
 
 // LM diagonal for the cameras: lam = clamp(s^2 Udd, min_d, max_d) / (radius s^2), or an explicit
@@ -866,10 +879,14 @@ __global__ void camera_damping_kernel(int Nc, const real *__restrict__ udiag,
                                       const real *__restrict__ scale_c,
                                       const real *__restrict__ lam_in, real radius, real min_d,
                                       real max_d, real *__restrict__ lam_out,
-                                      real *__restrict__ S_diag)
+                                      real *__restrict__ S_diag, const real *__restrict__ rhs,
+                                      real *__restrict__ rhs_copy, int *__restrict__ info)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 6 * Nc) return;
+    // set-up of the solve that follows, folded in: right-hand side into the solution vector, status cleared
+    if (rhs_copy) rhs_copy[i] = rhs[i];
+    if (info && i == 0) *info = 0;
     real l = real(0);
     if (lam_in) l = lam_in[i];
     else if (scale_c) {

@@ -110,3 +110,22 @@ def test_full_size_4096_pair(orc):
     assert np.array_equal(sw[2][order].view(np.uint32), got[2].view(np.uint32))
     assert mt.rescans() < 0.05 * 8192                    # the exact fallback stays rare
     same(got, orc.two_way_matching(d0, d1, 0.7))
+
+
+def test_full_size_batch_equals_single_pair_runs():
+    """BASELINE config 3 shape, a batch of 8 pairs: every pair's matches are bit-identical to the
+    same pair matched alone (pairs are independent; bands of different pairs share workgroup slots)."""
+    pairs = 8
+    data = [synth.make_descriptors(4096, 4096, seed=50 + p) for p in range(pairs)]
+    batch = vm.Matcher(pairs, 4096, 4096)
+    for p, (d0, d1) in enumerate(data):
+        batch.set_pair(p, d0, d1)
+    batch.run(pairs, 0.7)
+    single = vm.Matcher(1, 4096, 4096)
+    for p, (d0, d1) in enumerate(data):
+        single.set_pair(0, d0, d1)
+        single.run(1, 0.7)
+        a, b = batch.matches(p), single.matches(0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+        assert len(a[0]) > 1000

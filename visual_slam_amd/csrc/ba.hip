@@ -99,6 +99,8 @@ struct vs_ba {
     DevBuf<int> lm_cam_lo;      // first camera seen by each landmark-kernel workgroup (range staging)
     int lm_cam_span = 0;        // longest such range, 0 = range staging not used
     int n_multi_diag = 0, n_multi_off = 0;
+    int n_list_items = 0, n_small16 = 0, n_small32 = 0;   // items of the block kernel / of the small-block kernels
+    DevBuf<BlockItem> small_items;              // blocks of 1..16 entries, then blocks of 17..32
     DevBuf<BlockItem> items, diag_items;
     DevBuf<unsigned char> cam_used, pt_used;
     DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
@@ -278,7 +280,19 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     // Items are listed block row by block row (camera c's diagonal item(s), then its
     // off-diagonal blocks (c, c') in column order) so that a contiguous range of items is a band
     // of cameras.  With fixed points only the diagonal items are launched (diag_items).
-    std::vector<BlockItem> items, diag_items;
+    std::vector<BlockItem> items, diag_items, small_items, small32;
+    // Off-diagonal blocks of at most 32 entries go to the small-block kernels (several blocks per
+    // wave) when they hold a tenth of all entries or more: otherwise two more launches cost more
+    // than the idle lanes of those blocks in the block kernel.
+    bool pack_small = h->item_waves == 1 && getenv("VS_BA_NO_SMALL_BLOCKS") == nullptr;
+    if (pack_small) {
+        int64_t small_entries = 0;
+        for (int k = 0; k < nb_off; k++) {
+            const int nk = bptr[k + 1] - bptr[k];
+            if (nk <= 32) small_entries += nk;
+        }
+        pack_small = small_entries * 10 >= (int64_t)n_ent;
+    }
     std::vector<int> di_ptr((size_t)Nc + 1, 0), oi_ptr((size_t)nb_off + 1, 0);
     int n_diag_items = 0, n_off_items = 0;
     {
@@ -291,6 +305,12 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
             if (items.size() - first == 1) items[first].single = 1;
             for (size_t i = first; i < items.size(); i++) diag_items.push_back(items[i]);
             for (; k < nb_off && h->h_brow[k] == c; k++) {
+                const int nk = bptr[k + 1] - bptr[k];
+                if (pack_small && nk >= 1 && nk <= 32) {   // four / two such blocks share a wave of the small-block kernel
+                    (nk <= 16 ? small_items : small32).push_back(BlockItem{ k, bptr[k], bptr[k + 1], h->h_brow[k], h->h_bcol[k], 1, n_off_items++, 0 });
+                    oi_ptr[k + 1] = n_off_items;
+                    continue;
+                }
                 const size_t f2 = items.size();
                 for (int b = bptr[k]; b < bptr[k + 1]; b += ch)
                     items.push_back(BlockItem{ k, b, std::min(b + ch, bptr[k + 1]), h->h_brow[k], h->h_bcol[k], 0, n_off_items++, 0 });
@@ -324,6 +344,10 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     }
     h->n_diag_items = n_diag_items;
     h->n_off_items = n_off_items;
+    h->n_list_items = (int)items.size();
+    h->n_small16 = (int)small_items.size();
+    h->n_small32 = (int)small32.size();
+    small_items.insert(small_items.end(), small32.begin(), small32.end());
     h->n_multi_diag = h->n_multi_off = 0;          // blocks that are not exactly one item: finalize sums (or zeroes) them
     for (int c = 0; c < Nc; c++) h->n_multi_diag += di_ptr[c + 1] - di_ptr[c] != 1;   // empty blocks too:
     for (int k = 0; k < nb_off; k++) h->n_multi_off += oi_ptr[k + 1] - oi_ptr[k] != 1; // finalize zeroes them
@@ -369,6 +393,8 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     VS_TRY(up(h->ditem_ptr, di_ptr)); VS_TRY(up(h->oitem_ptr, oi_ptr));
     if (items.empty()) items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
     if (diag_items.empty()) diag_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
+    if (small_items.empty()) small_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
+    VS_TRY(h->small_items.upload(small_items.data(), small_items.size(), s));
     VS_TRY(h->items.upload(items.data(), items.size(), s));
     VS_TRY(h->diag_items.upload(diag_items.data(), diag_items.size(), s));
     VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
@@ -416,7 +442,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     mark(2);
     {
         // with fixed points only the camera (diagonal) items run
-        const int n_items = h->n_diag_items + (h->fix_points ? 0 : h->n_off_items);
+        const int n_items = h->fix_points ? h->n_diag_items : h->n_list_items;
         const BlockItem *list = h->fix_points ? h->diag_items.p : h->items.p;
         if (n_items > 0) {
             if (h->item_waves == 4)
@@ -430,6 +456,18 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
                                    h->Nc, h->nb_off, h->cost_partial.p, h->n_lm4_blocks);
             VS_TRY(launch_check("blocks_kernel"));
+        }
+        if (!h->fix_points && h->n_small16 > 0) {
+            hipLaunchKernelGGL(blocks_small_kernel<16>, dim3(div_up(h->n_small16, 4)), dim3(kWave), 0, h->stream,
+                               h->n_small16, h->small_items.p, h->K, h->cams.p, h->lmrec.p, h->bent.p, h->hub,
+                               h->hub_w.p, h->red.p, h->Nc, h->nb_off);
+            VS_TRY(launch_check("blocks_small_kernel"));
+        }
+        if (!h->fix_points && h->n_small32 > 0) {
+            hipLaunchKernelGGL(blocks_small_kernel<32>, dim3(div_up(h->n_small32, 2)), dim3(kWave), 0, h->stream,
+                               h->n_small32, h->small_items.p + h->n_small16, h->K, h->cams.p, h->lmrec.p, h->bent.p,
+                               h->hub, h->hub_w.p, h->red.p, h->Nc, h->nb_off);
+            VS_TRY(launch_check("blocks_small_kernel"));
         }
     }
     mark(3);

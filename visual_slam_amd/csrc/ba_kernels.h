@@ -778,6 +778,86 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
     }
 }
 
+// Off-diagonal blocks of at most L (16 or 32) entries, 64 / L to a wave: lane = (block lane / L,
+// entry lane % L).  The cameras differ between the blocks of a wave, so they live in vector
+// registers here.  The 36 sums of a block are reduced over its L lanes through LDS in a fixed order
+// and written straight into the reduce buffer (such a block is always a single item).
+template <int L>
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+blocks_small_kernel(int n_small, const BlockItem *__restrict__ items, Intr K,
+                    const CamData *__restrict__ cams, const real *__restrict__ lmrec,
+                    const int *__restrict__ bent, HuberObs hub, const real *__restrict__ hub_w,
+                    real *red, int Nc, int nb_off)
+{
+    __shared__ real lds[18 * kRedStride];
+    const int lane = threadIdx.x, q = lane / L, e = lane % L;
+    const int idx = blockIdx.x * (kWave / L) + q;
+    const BlockItem it = items[min(idx, n_small - 1)];
+    const bool have = idx < n_small && it.begin + e < it.end;
+    CamData A, B;
+    load_cam(cams, it.ca, A);
+    load_cam(cams, it.cb, B);
+    const int j = bent[have ? it.begin + e : it.begin];
+    real rec[10];
+    load_rec(lmrec, j, rec, 5);
+    const real *P = rec, *vi = rec + 3;
+    ObsLin oa, ob;
+    project_obs(A, P, real(0), real(0), K, oa);
+    project_obs(B, P, real(0), real(0), K, ob);
+    if (j == hub.pt) {
+        if (it.ca == hub.cam) scale_lin(oa, *hub_w);
+        if (it.cb == hub.cam) scale_lin(ob, *hub_w);
+    }
+    real Jca[12], Jcb[12], Jpa[6], Jpb[6], T[6];
+    camera_jac(A, oa, P, Jca);
+    point_jac(A, oa, Jpa);
+    camera_jac(B, ob, P, Jcb);
+    point_jac(B, ob, Jpb);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        T[3 * r] = Jpa[3 * r] * vi[0] + Jpa[3 * r + 1] * vi[1] + Jpa[3 * r + 2] * vi[2];
+        T[3 * r + 1] = Jpa[3 * r] * vi[1] + Jpa[3 * r + 1] * vi[3] + Jpa[3 * r + 2] * vi[4];
+        T[3 * r + 2] = Jpa[3 * r] * vi[2] + Jpa[3 * r + 1] * vi[4] + Jpa[3 * r + 2] * vi[5];
+    }
+    // M = -(Jp_a Vinv Jp_b^T); a lane without an entry contributes zeros
+    const real live = have ? real(-1) : real(0);
+    const real m00 = live * (T[0] * Jpb[0] + T[1] * Jpb[1] + T[2] * Jpb[2]);
+    const real m01 = live * (T[0] * Jpb[3] + T[1] * Jpb[4] + T[2] * Jpb[5]);
+    const real m10 = live * (T[3] * Jpb[0] + T[4] * Jpb[1] + T[5] * Jpb[2]);
+    const real m11 = live * (T[3] * Jpb[3] + T[4] * Jpb[4] + T[5] * Jpb[5]);
+    real B0[6], B1[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        B0[c] = c == 2 ? m01 * Jcb[8] : (c == 0 ? m00 * Jcb[0] : fma(m00, Jcb[c], m01 * Jcb[6 + c]));
+        B1[c] = c == 2 ? m11 * Jcb[8] : (c == 0 ? m10 * Jcb[0] : fma(m10, Jcb[c], m11 * Jcb[6 + c]));
+    }
+    real acc[kOffVals];
+#pragma unroll
+    for (int p = 0; p < 6; p++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            real t = real(0);
+            if (p != 0) t = fma(Jca[6 + p], B1[c], t);
+            if (p != 2) t = fma(Jca[p], B0[c], t);
+            acc[6 * p + c] = t;
+        }
+    const RedView rv = red_view(red, Nc, nb_off);
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 18; v++) lds[v * kRedStride + lane] = acc[18 * pass + v];
+        __syncthreads();
+        for (int v = e; v < 18; v += L) {
+            const real *cell = lds + v * kRedStride + L * q;
+            real c4[4] = { cell[0], cell[1], cell[2], cell[3] };
+#pragma unroll
+            for (int l = 4; l < L; l++) c4[l & 3] += cell[l];
+            if (idx < n_small) rv.S_off[(int64_t)it.blk * 36 + 18 * pass + v] = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+        }
+    }
+}
+
 // Sum of p[it * stride] for it in [i0, i1), added in item order; the loads go out four at a time
 // (a dependent load per addition would cost one memory latency per item).
 __device__ __forceinline__ real sum_partials_strided(const real *__restrict__ p, int stride, int i0, int i1)

@@ -240,6 +240,25 @@ def test_sharded_partial_systems_sum_to_the_whole():
     assert rel(acc_S, S) < 1e-12 and rel(acc_rhs, rhs) < 1e-12 and abs(acc_cost - cost) < 1e-12 * cost
 
 
+def test_sharded_small_blocks_sum_to_the_whole():
+    """600 cameras, 2 shared landmarks per camera pair: every off-diagonal block goes through the
+    small-block kernels, and shards leave some blocks of the global pattern empty."""
+    sc = synth.make_ba_scene(600, 3000, 4, band=16, seed=15)
+    d = np.full(3 * sc.Np, 0.3)
+    whole = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    whole.linearize(None, d)
+    br, bc, S, rhs, cost = whole.reduced_system()
+    acc_S, acc_rhs, acc_cost = 0, 0, 0
+    for r in range(3):
+        part = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=r, world=3)
+        part.linearize(None, d)
+        part.linearize(None, d)                      # twice: empty blocks must stay zero
+        b2, c2, S2, rhs2, cost2 = part.reduced_system()
+        assert np.array_equal(b2, br) and np.array_equal(c2, bc)
+        acc_S = acc_S + S2; acc_rhs = acc_rhs + rhs2; acc_cost += cost2
+    assert rel(acc_S, S) < 1e-12 and rel(acc_rhs, rhs) < 1e-12 and abs(acc_cost - cost) < 1e-12 * cost
+
+
 def test_allreduce_hook_is_called_and_sums(orc):
     """Two 'ranks' in one process: the hook adds the other shard's buffer, as an all-reduce would."""
     import ctypes

@@ -332,8 +332,8 @@ def cpu_baseline(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5shard", "c5"])
     ap.add_argument("--no-extra", action="store_true", help="skip the matcher leg and larger BA shapes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")

@@ -4,7 +4,7 @@ ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ivisual_slam_amd/csrc -Wall -Wno-unused-function
 CSRC := visual_slam_amd/csrc
 LIB := visual_slam_amd/lib/libvslam_hip.so
-OBJS := $(CSRC)/ba.o $(CSRC)/match.o $(CSRC)/track.o $(CSRC)/capi.o
+OBJS := $(CSRC)/ba.o $(CSRC)/match.o $(CSRC)/track.o $(CSRC)/comm.o $(CSRC)/capi.o
 HDRS := include/vslam_hip.h $(wildcard $(CSRC)/*.h)
 
 HOST := visual_slam_amd/host
@@ -18,7 +18,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 
 $(LIB): $(OBJS)
 	@mkdir -p visual_slam_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 # C++ host adapters keeping the reference's class interfaces, above the C ABI
 $(HOSTLIB): $(HOST)/optimizer.cc $(HOST)/superpoint_matcher.cc $(HOST)/*.h include/vslam_hip.h $(LIB)

@@ -135,10 +135,34 @@ int vs_ba_lm_step(vs_ba_handle h, double radius, double *dcam, double *dpt,
 /* ceres::Solve replacement (tracking.cc:110,152): runs LM to termination and updates the
  * handle's parameters in place. */
 int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summary);
-/* Multi-GPU hook: called by vs_ba_lm_step / vs_ba_solve after the local reduced system is formed
- * and before damping and solving; must sum `n` doubles at device pointer `buf` across ranks. */
+/* Multi-GPU hook for callers that bring their own collective (e.g. torch.distributed): called by
+ * vs_ba_lm_step / vs_ba_solve wherever a rank-global sum is needed (the reduce buffer, the step
+ * scalars, one slot per rank for maxima, the final gather of the points); must sum `n` doubles at
+ * device pointer `buf` across ranks, in place, and return 0.  The handle's stream is synchronised
+ * before each call.  Every rank must install a hook (or a communicator) before vs_ba_solve. */
 typedef int (*vs_allreduce_fn)(void *user, void *device_buf, int64_t n_doubles);
 int vs_ba_set_allreduce(vs_ba_handle h, vs_allreduce_fn fn, void *user);
+
+/* Native multi-GPU path (the reference is single-process; this is the landmark-sharded form of the
+ * Optimizer behind src/core/optimizer.h:24-36): one process or thread per GPU, each with a
+ * communicator over the same unique id.  Rank 0 calls vs_comm_unique_id and hands the
+ * VS_COMM_ID_BYTES bytes to the other ranks by any means (a file, MPI, a socket); then every rank
+ * calls vs_comm_create with its GPU current (a collective call: it returns once all ranks have
+ * joined).  A handle given a communicator (vs_ba_set_comm) sums its reduce buffer across ranks with
+ * an RCCL all-reduce enqueued on the handle's stream -- no host synchronisation, no callback -- and
+ * takes every LM decision (step scalars, gradient norm) from rank-global values, so all ranks
+ * iterate in lockstep and end with identical cameras; vs_ba_solve finally gathers the landmark
+ * shards so that every rank holds all points.  librccl is opened at run time on first use. */
+#define VS_COMM_ID_BYTES 128
+typedef struct vs_comm *vs_comm_handle;
+int vs_comm_unique_id(void *id_bytes);
+int vs_comm_create(vs_comm_handle *c, int32_t rank, int32_t world, const void *id_bytes);
+int vs_comm_destroy(vs_comm_handle c);
+/* In-place sum of n doubles at a device pointer across the ranks, enqueued on hip_stream. */
+int vs_comm_allreduce_sum(vs_comm_handle c, double *device_buf, int64_t n, void *hip_stream);
+/* NULL detaches.  The handle must have been given this rank's shard
+ * (vs_ba_set_observations_sharded with the communicator's rank and world). */
+int vs_ba_set_comm(vs_ba_handle h, vs_comm_handle c);
 
 /* Measurement aid (no counterpart in the reference): runs vs_ba_linearize `iters` times with HIP
  * events between its kernels, on the handle's stream, and returns average milliseconds:
@@ -204,7 +228,9 @@ int vs_match_stereo(const float *desc0, const int32_t *xy0, int32_t n0, const fl
  * Per-frame tracking helpers beside the matcher.  Poses are transform::Rigid3f as 7 floats:
  * translation x, y, z then rotation quaternion w, x, y, z (src/transform/rigid_transform.h:101-103);
  * K4 = fx, fy, cx, cy (config/config.yaml:12-16).  Pixel coordinates are cv::Point (n x 2 int32).
- * Host or device pointers; every call blocks until its results are in the output arrays.
+ * Array and pose/K4 arguments are host or device pointers (the small ones are copied to the host
+ * before use); the scalar counts n_removed / n_updated are HOST pointers.  Every call blocks until
+ * its results are in the output arrays.
  * ------------------------------------------------------------------------------------------ */
 
 /* Tracking::reprojection (src/core/tracking.cc:70-78) for n world points: float pinhole

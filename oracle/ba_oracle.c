@@ -520,7 +520,7 @@ int vo_solve(int Nc, int Np, int64_t No, const double *K4, double *t, double *rp
         int rc = vo_lm_step(Nc, Np, No, K4, t, rpy, pts, cam, pt, uv, huber_a, fix_points, radius,
                             min_d, max_d, sc, sp, dc, dp, &mcc);
         if (rc != 0 || !(mcc > 0.0)) {               /* invalid step */
-            if (++invalid > max_invalid) { term = 2; break; }
+            if (++invalid >= max_invalid) { term = 2; break; }   /* Ceres HandleInvalidStep: fails at the max-th consecutive one */
             radius *= 0.5;
             continue;
         }

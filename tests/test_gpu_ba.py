@@ -259,19 +259,16 @@ def test_sharded_small_blocks_sum_to_the_whole():
     assert rel(acc_S, S) < 1e-12 and rel(acc_rhs, rhs) < 1e-12 and abs(acc_cost - cost) < 1e-12 * cost
 
 
-def test_allreduce_hook_is_called_and_sums(orc):
-    """Two 'ranks' in one process: the hook adds the other shard's buffer, as an all-reduce would."""
-    import ctypes
-    sc = synth.make_ba_config("c1", seed=13)
-    ref = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
-    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
-    whole = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
-    dw, pw, mw = whole.lm_step(1e4)
-    assert rel(dw, d0) < 1e-6
-    calls = []
-    whole.set_allreduce(lambda p, n: calls.append(n))
-    whole.lm_step(1e4)
-    assert len(calls) >= 2 and calls[0] == whole.reduce_buffer()[1]
+def test_failure_after_five_consecutive_invalid_steps(orc):
+    """A non-finite observation makes every step invalid (NaN model cost change): like Ceres, the
+    loop gives up at the fifth consecutive invalid step (max_num_consecutive_invalid_steps = 5)."""
+    sc = synth.make_ba_config("c1", seed=15)
+    sc.uv = sc.uv.copy()
+    sc.uv[7, 0] = np.nan
+    ref, gpu = both(orc, sc)
+    out0, out1 = ref.solve(), gpu.solve()
+    assert out0["termination"] == 2 and out0["iterations"] == 5
+    assert out1["termination"] == 2 and out1["iterations"] == 5 and out1["successful_steps"] == 0
 
 
 def test_error_reporting():

@@ -129,3 +129,46 @@ def test_full_size_batch_equals_single_pair_runs():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
         assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
         assert len(a[0]) > 1000
+
+
+def test_descriptors_beyond_unit_norm_tie_at_the_clamp(orc):
+    """Rows of norm 1.5: inlier dots exceed 1, the reference clamps them to distance 0 and the
+    FIRST such column wins; the certainty band must send those rows through the exact scan."""
+    d0, d1 = synth.make_descriptors(700, 650, seed=33, duplicates=3)
+    d0 = (1.5 * d0).astype(np.float32); d1 = (1.5 * d1).astype(np.float32)
+    d1[40] = 1.3 * d1[600]; d1[41] = d1[600]          # several columns beyond the clamp for one row
+    d0[5] = -d0[6]
+    for th in (2.0, 0.7):
+        same(vm.two_way(d0, d1, th), orc.two_way_matching(d0, d1, th))
+    same(vm.two_way(-d0, d1, 2.5), orc.two_way_matching(-d0, d1, 2.5))   # lower clamp: distance 2 ties
+
+
+def test_config3_batch_of_64_pairs(orc):
+    """BASELINE config 3 as benchmarked: one batch of 64 pairs of 4096 x 4096.  Three pairs are
+    compared with the oracle; every pair must satisfy the reference loop's invariants."""
+    pairs, n = 64, 4096
+    mt = vm.Matcher(pairs, n, n)
+    data = {}
+    for p in range(pairs):
+        d0, d1 = synth.make_descriptors(n, n, seed=100 + p, duplicates=2 if p % 8 == 0 else 0)
+        if p in (0, 31, 63):
+            data[p] = (d0, d1)
+        mt.set_pair(p, d0, d1)
+    mt.run(pairs, 0.7)
+    for p in range(pairs):
+        oi, oj, od = mt.matches(p)
+        i0, i1 = mt.nn(p)
+        assert len(oi) > 1500 and np.all(np.diff(oi) > 0)
+        assert np.all(i1[oj] == oi) and np.all(i0[oi] == oj) and np.all(od < 0.7)
+    for p, (d0, d1) in data.items():
+        same(mt.matches(p), orc.two_way_matching(d0, d1, 0.7))
+
+
+def test_full_size_pair_with_ratio_test(orc):
+    """4096 x 4096 with the ratio test on (BASELINE config 3: "ratio + mutual check")."""
+    d0, d1 = synth.make_descriptors(4096, 4096, seed=41, duplicates=4)
+    for th, ratio in ((0.7, 0.8), (2.0, 0.95)):
+        got = vm.two_way(d0, d1, th, ratio)
+        same(got, orc.two_way_matching(d0, d1, th, ratio))
+    plain = vm.two_way(d0, d1, 0.7, 1.0)
+    assert 0 < len(got[0]) and len(vm.two_way(d0, d1, 0.7, 0.8)[0]) <= len(plain[0])

@@ -26,6 +26,7 @@ SYMBOLS = [
     "vs_match_two_way", "vs_match_stereo",
     "vs_reproject_points", "vs_search_projection", "vs_remove_outliers", "vs_compute_points3d",
     "vs_triangulate_tracks",
+    "vs_comm_unique_id", "vs_comm_create", "vs_comm_destroy", "vs_comm_allreduce_sum", "vs_ba_set_comm",
 ]
 
 
@@ -65,6 +66,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch's ROCm wheel carries private copies of the HIP and HSA runtimes.  A process that
+    # loads the system runtime first (through this library) and PyTorch afterwards ends up with two
+    # HSA runtimes and PyTorch then sees no GPU; loaded in the other order this library binds to
+    # the copy already in the process.  So when PyTorch is installed it is imported first.
+    if os.environ.get("VSLAM_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     path = os.environ.get("VSLAM_HIP_LIB", LIB_PATH)     # developer knob: an alternative build
     if not os.path.exists(path):
         raise ImportError("libvslam_hip.so not found at %s: build it with `make` (hipcc, gfx950); "

@@ -88,6 +88,9 @@ struct vs_ba {
     int64_t red_len = 0;
     vs_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    vs_comm *comm = nullptr;
+    int pt_lo = 0, pt_hi = 0;   // landmarks this handle linearises
+    DevBuf<real> rank_slots;    // one value per rank: maxima through a sum-only collective
 
     std::vector<int32_t> h_brow, h_bcol;
     hipEvent_t *prof_ev = nullptr;   // when set: 6 events recorded around linearize()'s kernels
@@ -167,6 +170,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         pt_hi = h->rank == h->world - 1 ? Np : std::min(bound(h->rank + 1), Np);
         if (pt_hi < pt_lo) pt_hi = pt_lo;
     }
+    h->pt_lo = pt_lo; h->pt_hi = pt_hi;
     const int64_t lo_pos = gptr[pt_lo], hi_pos = gptr[pt_hi];
     VS_CHECK(hi_pos - lo_pos < (int64_t)1 << 31, VS_ERR_UNSUPPORTED, "more than 2^31 observations on one GPU");
     const int No = (int)(hi_pos - lo_pos);
@@ -500,13 +504,34 @@ int ensure_state(vs_ba *h)
     return VS_OK;
 }
 
+// Sum of `n` doubles at device pointer `buf` over the landmark shards (in place): the native
+// communicator enqueues an RCCL all-reduce on the handle's stream, the callback form synchronises
+// the stream and calls out.
 int cross_gpu_sum(vs_ba *h, real *buf, int64_t n)
 {
+    if (h->comm) return comm_allreduce(h->comm, buf, n, false, h->stream);
     if (!h->allreduce) return VS_OK;
     VS_HIP(hipStreamSynchronize(h->stream));
     const int rc = h->allreduce(h->allreduce_user, buf, n);
     VS_CHECK(rc == 0, VS_ERR_HIP, "all-reduce callback failed with code %d", rc);
     return VS_OK;
+}
+
+bool is_sharded(const vs_ba *h) { return h->world > 1 && (h->comm || h->allreduce); }
+
+// Maximum over the shards of the double at device pointer `val` (in place).  The callback form
+// only sums: every rank writes its value into its own slot of a zeroed array, the array is summed
+// and the maximum of the slots is taken.
+int cross_gpu_max(vs_ba *h, real *val)
+{
+    if (!is_sharded(h)) return VS_OK;
+    if (h->comm) return comm_allreduce(h->comm, val, 1, true, h->stream);
+    if (h->rank_slots.n < (size_t)h->world) VS_TRY(h->rank_slots.alloc((size_t)h->world));
+    VS_HIP(hipMemsetAsync(h->rank_slots.p, 0, (size_t)h->world * sizeof(real), h->stream));
+    VS_HIP(hipMemcpyAsync(h->rank_slots.p + h->rank, val, sizeof(real), hipMemcpyDeviceToDevice, h->stream));
+    VS_TRY(cross_gpu_sum(h, h->rank_slots.p, h->world));
+    hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(64), 0, h->stream, h->world, h->rank_slots.p, val);
+    return launch_check("max_of_kernel");
 }
 
 struct StepScalars { real mcc, xnorm2, snorm2, cost_new; };
@@ -584,7 +609,8 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
     const int ncb = div_up(npar, 256);
     if (h->cand_partial.n < (size_t)ncb * 2) VS_TRY(h->cand_partial.alloc((size_t)ncb * 2 + 2));
     hipLaunchKernelGGL(candidate_kernel, dim3(ncb), dim3(256), 0, s, Nc, Np, (int)h->fix_points, h->t.p, h->rpy.p,
-                       h->pts.p, h->cam_used.p, h->pt_used.p, (int)(h->rank == 0), h->dcam.p, h->dpt.p,
+                       h->pts.p, h->cam_used.p, h->pt_used.p, (int)(h->rank == 0 || !is_sharded(h)),
+                       is_sharded(h) ? h->pt_lo : 0, is_sharded(h) ? h->pt_hi : h->Np, h->dcam.p, h->dpt.p,
                        h->t2.p, h->rpy2.p, h->pts2.p, h->cand_partial.p);
     VS_TRY(launch_check("candidate_kernel"));
     if (want_candidate_cost) {
@@ -616,6 +642,7 @@ int gradient_max(vs_ba *h, real *out)
     hipLaunchKernelGGL(gradient_max_kernel, dim3(1), dim3(256), 0, h->stream, (int64_t)6 * h->Nc, h->gc(),
                        h->fix_points ? (int64_t)0 : 3 * (int64_t)h->Np, h->lmrec.p, h->scalars.p + 4);
     VS_TRY(launch_check("gradient_max_kernel"));
+    VS_TRY(cross_gpu_max(h, h->scalars.p + 4));   // landmark gradients are local to a shard
     VS_HIP(hipMemcpyAsync(out, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, h->stream));
     VS_HIP(hipStreamSynchronize(h->stream));
     return VS_OK;
@@ -891,6 +918,16 @@ int vs_ba_set_allreduce(vs_ba_handle h, vs_allreduce_fn fn, void *user)
     return VS_OK;
 }
 
+int vs_ba_set_comm(vs_ba_handle h, vs_comm_handle c)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(c == nullptr || !h->have_obs || (comm_rank(c) == h->rank && comm_world(c) == h->world), VS_ERR_INVALID,
+             "communicator is rank %d of %d but the handle holds shard %d of %d", c ? comm_rank(c) : 0,
+             c ? comm_world(c) : 0, h->rank, h->world);
+    h->comm = c;
+    return VS_OK;
+}
+
 int vs_ba_lm_step(vs_ba_handle h, double radius, double *dcam, double *dpt, double *mcc)
 {
     VS_TRY(ensure_state(h));
@@ -946,7 +983,7 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
                 bool fail = false;
                 VS_TRY(lm_step_device(h, radius, o.min_lm_diagonal, o.max_lm_diagonal, &sc, &fail, true));
                 if (fail || !(sc.mcc > 0.0)) {
-                    if (++invalid > o.max_consecutive_invalid_steps) { term = 2; break; }
+                    if (++invalid >= o.max_consecutive_invalid_steps) { term = 2; break; }
                     radius *= 0.5;
                     continue;
                 }
@@ -981,6 +1018,14 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
             }
     }
     h->linearized = false;
+    if (is_sharded(h) && !h->fix_points) {
+        // every rank has updated only its own landmarks: zero the others and sum the shards
+        hipLaunchKernelGGL(mask_points_kernel, dim3(div_up(3 * (int64_t)h->Np, 256)), dim3(256), 0, s, h->Np, h->pt_lo,
+                           h->pt_hi, h->pts.p);
+        VS_TRY(launch_check("mask_points_kernel"));
+        VS_TRY(cross_gpu_sum(h, h->pts.p, 3 * (int64_t)h->Np));
+        VS_HIP(hipStreamSynchronize(s));
+    }
     if (summary) {
         summary->iterations = it; summary->successful_steps = nsucc; summary->termination = term;
         summary->initial_cost = cost0; summary->final_cost = cost; summary->final_radius = radius;

@@ -1068,6 +1068,25 @@ backsub_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
     if (threadIdx.x == 0) mcc_partial[blockIdx.x] = s;
 }
 
+// out = max of in[0..n) (single wave).
+__global__ void max_of_kernel(int n, const real *__restrict__ in, real *__restrict__ out)
+{
+    real m = in[0];
+    for (int i = threadIdx.x; i < n; i += 64) m = fmax(m, in[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (threadIdx.x == 0) *out = m;
+}
+
+// Zeroes the points outside [pt_lo, pt_hi) (the shard sum that follows gathers all points).
+__global__ void mask_points_kernel(int Np, int pt_lo, int pt_hi, real *__restrict__ pts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * (int64_t)Np) return;
+    const int j = (int)(i / 3);
+    if (j < pt_lo || j >= pt_hi) pts[i] = real(0);
+}
+
 // Candidate parameters x + d and the squared norms Ceres' parameter-tolerance test needs.
 // Only parameters that appear in a residual block are part of the problem (mask arrays).
 // out_partial: per block {|x|^2, |d|^2}.
@@ -1075,7 +1094,7 @@ __global__ void __launch_bounds__(256)
 candidate_kernel(int Nc, int Np, int fix_points, const real *__restrict__ t,
                  const real *__restrict__ rpy, const real *__restrict__ pts,
                  const unsigned char *__restrict__ cam_used,
-                 const unsigned char *__restrict__ pt_used, int count_cams,
+                 const unsigned char *__restrict__ pt_used, int count_cams, int pt_lo, int pt_hi,
                  const real *__restrict__ dcam, const real *__restrict__ dpt,
                  real *__restrict__ t2, real *__restrict__ rpy2, real *__restrict__ pts2,
                  real *__restrict__ out_partial)
@@ -1097,7 +1116,7 @@ candidate_kernel(int Nc, int Np, int fix_points, const real *__restrict__ t,
         const real x = pts[u];
         const real d = used ? dpt[u] : real(0);
         pts2[u] = x + d;
-        if (used) { xn = x * x; dn = d * d; }
+        if (used && j >= pt_lo && j < pt_hi) { xn = x * x; dn = d * d; }   // a shard counts its own landmarks
     }
     const real s0 = block_sum_256(xn, red);
     const real s1 = block_sum_256(dn, red);

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 #include "vslam_hip.h"
 
 namespace vs {
@@ -69,6 +70,12 @@ struct DevBuf {
         return VS_OK;
     }
 };
+
+// Collective on a vs_comm (comm.hip): in-place sum or max of n doubles at a device pointer, enqueued
+// on stream s (no host synchronisation).
+int comm_allreduce(vs_comm *c, double *buf, int64_t n, bool take_max, hipStream_t s);
+int comm_rank(const vs_comm *c);
+int comm_world(const vs_comm *c);
 
 static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -7,6 +7,7 @@
 // every kernel below touches in-band elements only.  The caller chooses ld as a multiple of 16
 // elements so that the 16-element row segments of the update tiles are aligned 128-byte lines.
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include "ba_kernels.h"
 
@@ -1014,17 +1015,24 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
 {
     const int window = bw < n ? bw : n;
     if (window <= kFusedMaxRows) {
-        static bool lds_limit_raised = false;     // dynamic LDS beyond the default limit
-        if (!lds_limit_raised) {
-            const int max_lds = kFusedMaxRows * kXS * (int)sizeof(real);
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_window_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
-                set_error("cannot raise the dynamic LDS limit of the single-workgroup Cholesky kernels");
-                return VS_ERR_HIP;
+        // dynamic LDS beyond the default limit: a per-device function attribute, set once per GPU
+        static std::mutex lds_mutex;
+        static bool lds_limit_raised[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return VS_ERR_HIP; }
+        {
+            std::lock_guard<std::mutex> lock(lds_mutex);
+            if (!lds_limit_raised[dev]) {
+                const int max_lds = kFusedMaxRows * kXS * (int)sizeof(real);
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_window_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
+                    set_error("cannot raise the dynamic LDS limit of the single-workgroup Cholesky kernels");
+                    return VS_ERR_HIP;
+                }
+                lds_limit_raised[dev] = true;
             }
-            lds_limit_raised = true;
         }
         const int buf_rows = (window + 15) & ~15;
         if (window <= kLookaheadMaxRows)

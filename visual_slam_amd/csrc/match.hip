@@ -13,7 +13,10 @@
 // reference's first minimum and only its distance is recomputed exactly; otherwise the row/column
 // is re-decided by an exact scan that replays the reference arithmetic (sequential fp64
 // accumulation, narrowing, clamp, sqrtf).  Indices and distances are therefore bit-identical to
-// the reference path.
+// that arithmetic.  cv::Mat::dot itself is not in the reference tree: builds of OpenCV that
+// accumulate in float SIMD lanes round differently, so parity with OpenCV's dot is unpinned.
+// Descriptors need not have unit norm (scores beyond the clamp are treated as the ties they are),
+// but their entries must stay below 255 in magnitude (fp16 range after the 2^8 prescale).
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -111,6 +114,10 @@ __device__ __forceinline__ float pair_band(const unsigned *__restrict__ stats, i
     const float eps = ea * (nb + eb) + na * eb + kAccumRel * na * nb;
     return 2.0f * eps * 1.002f + kCollapse * kDotScale;
 }
+
+// The reference clamps the dot to [-1, 1] before the distance, so every score beyond the clamp
+// ties (the first index wins): certainty tests compare scores clamped the same way.
+__device__ __forceinline__ float clamp_score(float s) { return fminf(fmaxf(s, -kDotScale), kDotScale); }
 
 // plain VALU max / median without the canonicalising extra instructions the compiler adds
 __device__ __forceinline__ float vmax(float a, float b)
@@ -511,7 +518,7 @@ merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
     const int win = parts > 0 ? partial_index(v.is_row, pbest, b1) : -1;
     if (v.is_row) idx0[(int64_t)pair * n0_pad + v.self] = win;
     else idx1[(int64_t)pair * n1_pad + v.self] = win;
-    const bool uncertain = (force_rows && v.is_row) || !(b1 - b2 > pair_band(stats, pair));
+    const bool uncertain = (force_rows && v.is_row) || !(clamp_score(b1) - clamp_score(b2) > pair_band(stats, pair));
     if (uncertain && parts > 0) {
         const int slot = atomicAdd(rescan_count, 1);
         rescan_list[2 * (int64_t)slot] = pair;
@@ -558,6 +565,7 @@ rescan_items_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
         for (int p = lane; p < parts; p += 64) item_best = fmaxf(item_best, v.part[p * v.stride].x);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) item_best = fmaxf(item_best, __shfl_xor(item_best, off, 64));
+        item_best = clamp_score(item_best);
 
         unsigned long long key = ~0ull;
         // exact distance of candidate `c` for this lane given the finished dot
@@ -573,8 +581,8 @@ rescan_items_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
             const int p = pbase + lane;
             float2 q = make_float2(kNegInf, kNegInf);
             if (p < parts) q = v.part[p * v.stride];
-            const bool in_band = p < parts && item_best - q.x <= band;
-            const bool whole = in_band && item_best - q.y <= band;
+            const bool in_band = p < parts && item_best - clamp_score(q.x) <= band;
+            const bool whole = in_band && item_best - clamp_score(q.y) <= band;
             const bool single = in_band && !whole;
             if (__ballot(single)) {
                 const int c = single ? partial_index(v.is_row, p, q.x) : 0;
@@ -859,16 +867,28 @@ int vs_matcher_set_pair(vs_matcher_handle m, int32_t pair, const float *desc0, i
     return VS_OK;
 }
 
-int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float ratio)
+// Device buffers one matcher run works on (all pairs of a batch share the row pads).
+struct MatchView {
+    int n0_pad, n1_pad;
+    const float *d0, *d1;            // fp32 descriptors, pair p at p * n_pad * 256
+    _Float16 *a16, *b16;             // their fp16 images (split_kernel)
+    unsigned *stats;                 // 4 per pair, see pair_band()
+    const int2 *xy0, *xy1;           // keypoints (stereo mask) or unused
+    PairDims *dims;
+    float2 *row_part, *col_part;     // (best, second) packed scores per item and 64-chunk
+    float *dist0, *dist1, *second0;
+    int *idx0, *idx1, *rescan_list, *rescan_count;
+    int *out_i, *out_j, *out_n;
+    float *out_d;
+};
+
+// The matcher pipeline on pairs [0, n_pairs) of `v`: scores + fused top-2, merge, exact
+// re-decisions, mutual check + compaction.  Launches only; allocates nothing.
+static int run_match(const MatchView &v, int n_pairs, bool masked, float nn_thresh, float ratio,
+                     hipStream_t s, hipEvent_t *prof_ev)
 {
-    VS_CHECK(m != nullptr, VS_ERR_INVALID, "null handle");
-    VS_CHECK(n_pairs > 0 && n_pairs <= m->max_pairs, VS_ERR_INVALID, "n_pairs %d out of range (1..%d)", n_pairs, m->max_pairs);
-    bool masked = m->h_masked[0];
-    for (int p = 1; p < n_pairs; p++)
-        VS_CHECK((bool)m->h_masked[p] == masked, VS_ERR_INVALID, "a batch must be all two-way or all stereo pairs");
-    hipStream_t s = m->stream;
-    auto mark = [&](int i) { if (m->prof_ev) (void)hipEventRecord(m->prof_ev[i], s); };
-    const int r0 = m->n0_pad, r1 = m->n1_pad;
+    auto mark = [&](int i) { if (prof_ev) (void)hipEventRecord(prof_ev[i], s); };
+    const int r0 = v.n0_pad, r1 = v.n1_pad;
     // column tiles per workgroup: whole rows of tiles when that still gives every CU several
     // workgroups, otherwise split the tile rows
     const int ntr = r0 / kBM, ntc = r1 / kBN;
@@ -878,52 +898,76 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
     mark(0);
     const dim3 grid(n_pairs * ntr * splits);
     if (masked)
-        hipLaunchKernelGGL(dot_top2_kernel<true>, grid, dim3(256), 0, s, m->a16.p, m->b16.p, m->dims.p, m->xy0.p,
-                           m->xy1.p, r0, r1, tiles_per_wg, m->row_part.p, m->col_part.p);
+        hipLaunchKernelGGL(dot_top2_kernel<true>, grid, dim3(256), 0, s, v.a16, v.b16, v.dims, v.xy0,
+                           v.xy1, r0, r1, tiles_per_wg, v.row_part, v.col_part);
     else
-        hipLaunchKernelGGL(dot_top2_kernel<false>, grid, dim3(256), 0, s, m->a16.p, m->b16.p, m->dims.p, m->xy0.p,
-                           m->xy1.p, r0, r1, tiles_per_wg, m->row_part.p, m->col_part.p);
+        hipLaunchKernelGGL(dot_top2_kernel<false>, grid, dim3(256), 0, s, v.a16, v.b16, v.dims, v.xy0,
+                           v.xy1, r0, r1, tiles_per_wg, v.row_part, v.col_part);
     VS_TRY(launch_ok("dot_top2_kernel"));
     mark(1);
     const int force = ratio < 1.0f ? 1 : 0;   // the ratio test needs every row's exact second best
-    VS_HIP(hipMemsetAsync(m->rescan_count.p, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0 + r1, 256), n_pairs), dim3(256), 0, s, m->dims.p, r0, r1,
-                       m->row_part.p, m->col_part.p, m->stats.p, m->idx0.p, m->idx1.p, m->rescan_list.p,
-                       m->rescan_count.p, force);
+    VS_HIP(hipMemsetAsync(v.rescan_count, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0 + r1, 256), n_pairs), dim3(256), 0, s, v.dims, r0, r1,
+                       v.row_part, v.col_part, v.stats, v.idx0, v.idx1, v.rescan_list,
+                       v.rescan_count, force);
     VS_TRY(launch_ok("merge_kernel"));
     mark(2);
     if (force) {
         // ratio test: every row needs its exact second-best distance -> whole-row scans
         if (masked)
-            hipLaunchKernelGGL(rescan_kernel<true>, dim3(2048), dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
-                               m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->idx0.p, m->idx1.p,
-                               m->dist0.p, m->dist1.p, m->second0.p);
+            hipLaunchKernelGGL(rescan_kernel<true>, dim3(2048), dim3(256), 0, s, v.d0, v.d1, v.dims, v.xy0,
+                               v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.idx0, v.idx1,
+                               v.dist0, v.dist1, v.second0);
         else
-            hipLaunchKernelGGL(rescan_kernel<false>, dim3(2048), dim3(256), 0, s, m->d0.p, m->d1.p, m->dims.p, m->xy0.p,
-                               m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->idx0.p, m->idx1.p,
-                               m->dist0.p, m->dist1.p, m->second0.p);
+            hipLaunchKernelGGL(rescan_kernel<false>, dim3(2048), dim3(256), 0, s, v.d0, v.d1, v.dims, v.xy0,
+                               v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.idx0, v.idx1,
+                               v.dist0, v.dist1, v.second0);
     } else {
         const dim3 dgrid(div_up(r0, 64), n_pairs);
         if (masked) {
-            hipLaunchKernelGGL(rescan_items_kernel<true>, dim3(8192), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
-                               m->xy0.p, m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->row_part.p,
-                               m->col_part.p, m->stats.p, m->idx0.p, m->idx1.p);
-            hipLaunchKernelGGL(mutual_distance_kernel<true>, dgrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
-                               m->xy0.p, m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->dist0.p);
+            hipLaunchKernelGGL(rescan_items_kernel<true>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
+                               v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
+                               v.col_part, v.stats, v.idx0, v.idx1);
+            hipLaunchKernelGGL(mutual_distance_kernel<true>, dgrid, dim3(64), 0, s, v.d0, v.d1, v.dims,
+                               v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0);
         } else {
-            hipLaunchKernelGGL(rescan_items_kernel<false>, dim3(8192), dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
-                               m->xy0.p, m->xy1.p, r0, r1, m->rescan_list.p, m->rescan_count.p, m->row_part.p,
-                               m->col_part.p, m->stats.p, m->idx0.p, m->idx1.p);
-            hipLaunchKernelGGL(mutual_distance_kernel<false>, dgrid, dim3(64), 0, s, m->d0.p, m->d1.p, m->dims.p,
-                               m->xy0.p, m->xy1.p, r0, r1, m->idx0.p, m->idx1.p, m->dist0.p);
+            hipLaunchKernelGGL(rescan_items_kernel<false>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
+                               v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
+                               v.col_part, v.stats, v.idx0, v.idx1);
+            hipLaunchKernelGGL(mutual_distance_kernel<false>, dgrid, dim3(64), 0, s, v.d0, v.d1, v.dims,
+                               v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0);
         }
     }
     VS_TRY(launch_ok("exact kernels"));
     mark(3);
-    hipLaunchKernelGGL(compact_kernel, dim3(n_pairs), dim3(1024), 0, s, m->dims.p, r0, r1, m->idx0.p, m->idx1.p,
-                       m->dist0.p, m->second0.p, nn_thresh, ratio, m->out_i.p, m->out_j.p, m->out_d.p, m->out_n.p);
+    hipLaunchKernelGGL(compact_kernel, dim3(n_pairs), dim3(1024), 0, s, v.dims, r0, r1, v.idx0, v.idx1,
+                       v.dist0, v.second0, nn_thresh, ratio, v.out_i, v.out_j, v.out_d, v.out_n);
     VS_TRY(launch_ok("compact_kernel"));
     mark(4);
+    return VS_OK;
+}
+
+static MatchView handle_view(vs_matcher *m)
+{
+    MatchView v;
+    v.n0_pad = m->n0_pad; v.n1_pad = m->n1_pad;
+    v.d0 = m->d0.p; v.d1 = m->d1.p; v.a16 = m->a16.p; v.b16 = m->b16.p; v.stats = m->stats.p;
+    v.xy0 = m->xy0.p; v.xy1 = m->xy1.p; v.dims = m->dims.p;
+    v.row_part = m->row_part.p; v.col_part = m->col_part.p;
+    v.dist0 = m->dist0.p; v.dist1 = m->dist1.p; v.second0 = m->second0.p;
+    v.idx0 = m->idx0.p; v.idx1 = m->idx1.p; v.rescan_list = m->rescan_list.p; v.rescan_count = m->rescan_count.p;
+    v.out_i = m->out_i.p; v.out_j = m->out_j.p; v.out_n = m->out_n.p; v.out_d = m->out_d.p;
+    return v;
+}
+
+int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float ratio)
+{
+    VS_CHECK(m != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(n_pairs > 0 && n_pairs <= m->max_pairs, VS_ERR_INVALID, "n_pairs %d out of range (1..%d)", n_pairs, m->max_pairs);
+    bool masked = m->h_masked[0];
+    for (int p = 1; p < n_pairs; p++)
+        VS_CHECK((bool)m->h_masked[p] == masked, VS_ERR_INVALID, "a batch must be all two-way or all stereo pairs");
+    VS_TRY(run_match(handle_view(m), n_pairs, masked, nn_thresh, ratio, m->stream, m->prof_ev));
     m->ran = true;
     return VS_OK;
 }

@@ -518,6 +518,28 @@ int require_device()
     return VS_OK;
 }
 
+// Small by-value arguments (poses, intrinsics) may arrive as host or device pointers like every
+// other argument: they are copied into host temporaries before the host reads them.
+struct HostArgs {
+    float pose[2][7];
+    float K4[4];
+};
+int stage_args(HostArgs &a, const float *pose1, const float *pose2, const float *K4)
+{
+    VS_HIP(hipMemcpy(a.pose[0], pose1, 7 * sizeof(float), hipMemcpyDefault));
+    if (pose2) VS_HIP(hipMemcpy(a.pose[1], pose2, 7 * sizeof(float), hipMemcpyDefault));
+    VS_HIP(hipMemcpy(a.K4, K4, 4 * sizeof(float), hipMemcpyDefault));
+    return VS_OK;
+}
+
+template <typename T>
+int fill_output(T *dst, size_t count, T value)
+{
+    std::vector<T> h(count, value);
+    if (count) VS_HIP(hipMemcpy(dst, h.data(), count * sizeof(T), hipMemcpyDefault));
+    return VS_OK;
+}
+
 template <typename T>
 int upload(DevBuf<T> &buf, const void *src, size_t count)
 {
@@ -540,8 +562,10 @@ int vs_reproject_points(const float *pose, const float *K4, const float *xyz, in
     DevBuf<int2> d_xy;
     VS_TRY(upload(d_xyz, xyz, (size_t)n * 3));
     VS_TRY(d_xy.alloc(n));
-    const Intr4 K{ K4[0], K4[1], K4[2], K4[3] };
-    hipLaunchKernelGGL(reproject_kernel, dim3(div_up(n, 256)), dim3(256), 0, 0, make_pose(pose), K, d_xyz.p, n, d_xy.p);
+    HostArgs ha;
+    VS_TRY(stage_args(ha, pose, nullptr, K4));
+    const Intr4 K{ ha.K4[0], ha.K4[1], ha.K4[2], ha.K4[3] };
+    hipLaunchKernelGGL(reproject_kernel, dim3(div_up(n, 256)), dim3(256), 0, 0, make_pose(ha.pose[0]), K, d_xyz.p, n, d_xy.p);
     VS_TRY(launch_ok("reproject_kernel"));
     VS_HIP(hipMemcpy(xy, d_xy.p, (size_t)n * sizeof(int2), hipMemcpyDefault));
     return VS_OK;
@@ -556,11 +580,8 @@ int vs_search_projection(const float *pose, const float *K4, const float *tp_xyz
     VS_CHECK(n_tp == 0 || (tp_xyz && tp_desc && tracks), VS_ERR_INVALID, "null tracked-point arrays");
     VS_CHECK(n_keys == 0 || (key_xy && key_desc && claimed), VS_ERR_INVALID, "null keypoint arrays");
     if (n_tp == 0) return VS_OK;
-    if (n_keys == 0) {
-        for (int i = 0; i < n_tp; i++) tracks[i] = -1;
-        return VS_OK;
-    }
     VS_TRY(require_device());
+    if (n_keys == 0) return fill_output<int32_t>(tracks, (size_t)n_tp, -1);
     DevBuf<float> d_xyz, d_tdesc, d_kdesc;
     DevBuf<int2> d_re, d_kxy;
     DevBuf<unsigned long long> d_cand;
@@ -572,19 +593,24 @@ int vs_search_projection(const float *pose, const float *K4, const float *tp_xyz
     VS_TRY(upload(d_kxy, key_xy, (size_t)n_keys));
     VS_TRY(d_re.alloc(n_tp)); VS_TRY(d_cand.alloc((size_t)n_tp * kCandCap)); VS_TRY(d_ncand.alloc(n_tp));
     VS_TRY(d_over.alloc(n_tp)); VS_TRY(d_owner.alloc(n_keys)); VS_TRY(d_done.alloc(n_tp)); VS_TRY(d_tracks.alloc(n_tp));
+    std::vector<uint8_t> b_claimed(n_keys);
+    VS_HIP(hipMemcpy(b_claimed.data(), claimed, (size_t)n_keys, hipMemcpyDefault));
     std::vector<int> h_claimed(n_keys);
-    for (int j = 0; j < n_keys; j++) h_claimed[j] = claimed[j] ? 1 : 0;
+    for (int j = 0; j < n_keys; j++) h_claimed[j] = b_claimed[j] ? 1 : 0;
     VS_TRY(upload(d_claimed, h_claimed.data(), (size_t)n_keys));
-    const Intr4 K{ K4[0], K4[1], K4[2], K4[3] };
-    hipLaunchKernelGGL(reproject_kernel, dim3(div_up(n_tp, 256)), dim3(256), 0, 0, make_pose(pose), K, d_xyz.p, n_tp, d_re.p);
+    HostArgs ha;
+    VS_TRY(stage_args(ha, pose, nullptr, K4));
+    const Intr4 K{ ha.K4[0], ha.K4[1], ha.K4[2], ha.K4[3] };
+    hipLaunchKernelGGL(reproject_kernel, dim3(div_up(n_tp, 256)), dim3(256), 0, 0, make_pose(ha.pose[0]), K, d_xyz.p, n_tp, d_re.p);
     hipLaunchKernelGGL(gated_nn_kernel<kWindow>, dim3(n_tp), dim3(64), 0, 0, d_tdesc.p, d_re.p, n_tp, d_kdesc.p, d_kxy.p,
-                       n_keys, 2.0f * K4[2], 2.0f * K4[3], radius, accept, d_claimed.p, d_cand.p, d_ncand.p, d_over.p, (int *)nullptr);
+                       n_keys, 2.0f * ha.K4[2], 2.0f * ha.K4[3], radius, accept, d_claimed.p, d_cand.p, d_ncand.p, d_over.p, (int *)nullptr);
     hipLaunchKernelGGL(greedy_resolve_kernel, dim3(1), dim3(1024), 0, 0, n_tp, n_keys, d_cand.p, d_ncand.p, d_over.p,
                        d_tdesc.p, d_re.p, d_kdesc.p, d_kxy.p, radius, accept, d_claimed.p, d_owner.p, d_done.p, d_tracks.p);
     VS_TRY(launch_ok("search projection kernels"));
     VS_HIP(hipMemcpy(tracks, d_tracks.p, (size_t)n_tp * sizeof(int), hipMemcpyDefault));
     VS_HIP(hipMemcpy(h_claimed.data(), d_claimed.p, (size_t)n_keys * sizeof(int), hipMemcpyDefault));
-    for (int j = 0; j < n_keys; j++) claimed[j] = h_claimed[j] ? 1 : 0;
+    for (int j = 0; j < n_keys; j++) b_claimed[j] = h_claimed[j] ? 1 : 0;
+    VS_HIP(hipMemcpy(claimed, b_claimed.data(), (size_t)n_keys, hipMemcpyDefault));
     return VS_OK;
 }
 
@@ -606,8 +632,10 @@ int vs_remove_outliers(const float *pose, const float *K4, const float *tp_xyz, 
     VS_TRY(upload(d_tracks, tracks, (size_t)n_tp));
     VS_TRY(d_removed.alloc(1));
     VS_HIP(hipMemset(d_removed.p, 0, sizeof(int)));
-    const Intr4 K{ K4[0], K4[1], K4[2], K4[3] };
-    hipLaunchKernelGGL(remove_outliers_kernel, dim3(div_up(n_tp, 256)), dim3(256), 0, 0, make_pose(pose), K, d_xyz.p, n_tp,
+    HostArgs ha;
+    VS_TRY(stage_args(ha, pose, nullptr, K4));
+    const Intr4 K{ ha.K4[0], ha.K4[1], ha.K4[2], ha.K4[3] };
+    hipLaunchKernelGGL(remove_outliers_kernel, dim3(div_up(n_tp, 256)), dim3(256), 0, 0, make_pose(ha.pose[0]), K, d_xyz.p, n_tp,
                        d_kxy.p, n_keys, max_dist, d_tracks.p, d_removed.p);
     VS_TRY(launch_ok("remove_outliers_kernel"));
     VS_HIP(hipMemcpy(tracks, d_tracks.p, (size_t)n_tp * sizeof(int), hipMemcpyDefault));
@@ -635,10 +663,12 @@ int vs_compute_points3d(const float *desc0, const int32_t *xy0, int32_t n0, cons
     VS_TRY(upload(d_xy0, xy0, (size_t)n0));
     VS_TRY(upload(d_xy1, xy1, (size_t)n1));
     VS_TRY(d_loc.alloc(n0)); VS_TRY(d_good.alloc(n0)); VS_TRY(d_pw.alloc((size_t)n0 * 3));
-    const Intr4 K{ K4[0], K4[1], K4[2], K4[3] };
+    HostArgs ha;
+    VS_TRY(stage_args(ha, pose, nullptr, K4));
+    const Intr4 K{ ha.K4[0], ha.K4[1], ha.K4[2], ha.K4[3] };
     hipLaunchKernelGGL(gated_nn_kernel<kStereo>, dim3(n0), dim3(64), 0, 0, d_d0.p, d_xy0.p, n0, d_d1.p, d_xy1.p, n1,
                        0.f, 0.f, 0.f, 0.0, (const int *)nullptr, (unsigned long long *)nullptr, (int *)nullptr, (unsigned char *)nullptr, d_loc.p);
-    hipLaunchKernelGGL(points3d_kernel, dim3(div_up(n0, 256)), dim3(256), 0, 0, make_pose(pose), K, baseline_fx, d_xy0.p,
+    hipLaunchKernelGGL(points3d_kernel, dim3(div_up(n0, 256)), dim3(256), 0, 0, make_pose(ha.pose[0]), K, baseline_fx, d_xy0.p,
                        n0, d_xy1.p, d_loc.p, d_good.p, d_pw.p);
     VS_TRY(launch_ok("computePoint3d kernels"));
     VS_HIP(hipMemcpy(good, d_good.p, (size_t)n0, hipMemcpyDefault));
@@ -657,11 +687,8 @@ int vs_triangulate_tracks(const float *pose1, const float *pose2, const float *K
     VS_CHECK((n_keys1 == 0 || key_xy1) && (n_keys2 == 0 || key_xy2), VS_ERR_INVALID, "null keypoint arrays");
     if (n_updated) *n_updated = 0;
     if (n_tp == 0) return VS_OK;
-    if (n_keys1 == 0 || n_keys2 == 0) {
-        if (updated) for (int i = 0; i < n_tp; i++) updated[i] = 0;
-        return VS_OK;
-    }
     VS_TRY(require_device());
+    if (n_keys1 == 0 || n_keys2 == 0) return updated ? fill_output<uint8_t>(updated, (size_t)n_tp, 0) : VS_OK;
     DevBuf<float> d_xyz;
     DevBuf<int2> d_k1, d_k2;
     DevBuf<int> d_t1, d_t2, d_count;
@@ -673,8 +700,10 @@ int vs_triangulate_tracks(const float *pose1, const float *pose2, const float *K
     VS_TRY(upload(d_t2, tracks2, (size_t)n_tp));
     VS_TRY(d_upd.alloc(n_tp)); VS_TRY(d_count.alloc(1));
     VS_HIP(hipMemset(d_count.p, 0, sizeof(int)));
-    const Intr4 K{ K4[0], K4[1], K4[2], K4[3] };
-    hipLaunchKernelGGL(triangulate_kernel, dim3(div_up(n_tp, 128)), dim3(128), 0, 0, make_pose(pose1), make_pose(pose2), K,
+    HostArgs ha;
+    VS_TRY(stage_args(ha, pose1, pose2, K4));
+    const Intr4 K{ ha.K4[0], ha.K4[1], ha.K4[2], ha.K4[3] };
+    hipLaunchKernelGGL(triangulate_kernel, dim3(div_up(n_tp, 128)), dim3(128), 0, 0, make_pose(ha.pose[0]), make_pose(ha.pose[1]), K,
                        d_k1.p, n_keys1, d_t1.p, d_k2.p, n_keys2, d_t2.p, n_tp, d_xyz.p, d_upd.p, d_count.p);
     VS_TRY(launch_ok("triangulate_kernel"));
     VS_HIP(hipMemcpy(xyz, d_xyz.p, (size_t)n_tp * 3 * sizeof(float), hipMemcpyDefault));

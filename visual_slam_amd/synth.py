@@ -98,8 +98,11 @@ def make_ba_scene(Nc, Np, k_mean, band=None, seed=0, k_jitter=2, cam_step=0.05, 
     pt = np.concatenate(pts_idx).astype(np.int32)
     uv, _ = project(pts_gt[pt], t_gt[cam], rpy_gt[cam])
     uv = np.rint(uv + rng.normal(0, noise_px, uv.shape))
-    t0 = t_gt + rng.normal(0, pose_noise[0], t_gt.shape)
+    # the initial pose is the true one moved by pose_noise[0] and turned by pose_noise[1] ABOUT THE
+    # CAMERA CENTRE (t = -R c: turning R while keeping t would swing a camera that is hundreds of
+    # metres from the origin by metres)
     rpy0 = rpy_gt + rng.normal(0, pose_noise[1], rpy_gt.shape)
+    t0 = -np.einsum("nij,nj->ni", rpy_to_R(rpy0), cw + rng.normal(0, pose_noise[0], cw.shape))
     pts0 = pts_gt + rng.normal(0, pt_noise, pts_gt.shape)
     return BAScene(cam=cam, pt=pt, uv=uv, t0=t0, rpy0=rpy0, pts0=pts0, t_gt=t_gt, rpy_gt=rpy_gt,
                    pts_gt=pts_gt, K=np.array([FX, FY, CX, CY]))

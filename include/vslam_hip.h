@@ -224,6 +224,21 @@ int vs_match_stereo(const float *desc0, const int32_t *xy0, int32_t n0, const fl
                     const int32_t *xy1, int32_t n1, float nn_thresh, float ratio, int32_t *out_i,
                     int32_t *out_j, float *out_d, int32_t *out_n);
 
+/* Allocation-free form of vs_match_two_way.  It has no counterpart in the reference: it is for
+ * callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  Same results as vs_match_two_way, bit for bit.  All of
+ * desc0, desc1, out_i, out_j, out_d (each >= n0 entries) and out_n are DEVICE pointers; the
+ * descriptors are read in place.  n0, n1 <= VS_MATCH_NOALLOC_MAX_N, larger sizes return
+ * VS_ERR_INVALID.  The kernels are enqueued on hip_stream (NULL = the null stream) and the call
+ * returns without waiting: the outputs are complete when the stream reaches that point.  The
+ * intermediate buffers live in one statically allocated device array (about 3.2 MB per GPU, held
+ * until the process ends) that every call on a GPU shares: two calls that overlap on one GPU
+ * (different streams or threads) race; calls on one stream are safe. */
+#define VS_MATCH_NOALLOC_MAX_N 2048
+int vs_match_two_way_noalloc(const float *desc0, int32_t n0, const float *desc1, int32_t n1,
+                             float nn_thresh, float ratio, int32_t *out_i, int32_t *out_j,
+                             float *out_d, int32_t *out_n, void *hip_stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-frame tracking helpers beside the matcher.  Poses are transform::Rigid3f as 7 floats:
  * translation x, y, z then rotation quaternion w, x, y, z (src/transform/rigid_transform.h:101-103);

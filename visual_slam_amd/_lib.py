@@ -26,6 +26,7 @@ SYMBOLS = [
     "vs_match_two_way", "vs_match_stereo",
     "vs_reproject_points", "vs_search_projection", "vs_remove_outliers", "vs_compute_points3d",
     "vs_triangulate_tracks",
+    "vs_match_two_way_noalloc",
     "vs_comm_unique_id", "vs_comm_create", "vs_comm_destroy", "vs_comm_allreduce_sum", "vs_ba_set_comm",
 ]
 

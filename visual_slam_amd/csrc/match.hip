@@ -19,6 +19,7 @@
 // but their entries must stay below 255 in magnitude (fp16 range after the 2^8 prescale).
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1076,6 +1077,103 @@ int vs_match_stereo(const float *desc0, const int32_t *xy0, int32_t n0, const fl
     if (out_n && (n0 == 0 || n1 == 0)) { *out_n = 0; return VS_OK; }
     VS_CHECK(xy0 && xy1, VS_ERR_INVALID, "stereo matching needs keypoint coordinates");
     return match_once(desc0, xy0, n0, desc1, xy1, n1, nn_thresh, ratio, out_i, out_j, out_d, out_n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Allocation-free one-shot two-way matcher.  Everything vs_match_two_way keeps in a freshly
+// allocated handle (fp16 images, top-2 partials, nearest-neighbour and rescan lists) lives in one
+// file-scope device array; the caller's descriptors are read in place.
+constexpr int kNoAllocMaxN = VS_MATCH_NOALLOC_MAX_N;
+constexpr size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+constexpr int kNaPad0 = (kNoAllocMaxN + kBM - 1) / kBM * kBM, kNaPad1 = (kNoAllocMaxN + kBN - 1) / kBN * kBN;
+constexpr size_t kNaA16 = 0;
+constexpr size_t kNaB16 = kNaA16 + align256((size_t)kNaPad0 * kD * 2);
+constexpr size_t kNaRowPart = kNaB16 + align256((size_t)kNaPad1 * kD * 2);
+constexpr size_t kNaColPart = kNaRowPart + align256((size_t)(kNaPad1 / kSub) * kNaPad0 * sizeof(float2));
+constexpr size_t kNaIdx0 = kNaColPart + align256((size_t)(kNaPad0 / kSub) * kNaPad1 * sizeof(float2));
+constexpr size_t kNaIdx1 = kNaIdx0 + align256((size_t)kNaPad0 * 4);
+constexpr size_t kNaDist0 = kNaIdx1 + align256((size_t)kNaPad1 * 4);
+constexpr size_t kNaDist1 = kNaDist0 + align256((size_t)kNaPad0 * 4);
+constexpr size_t kNaSecond0 = kNaDist1 + align256((size_t)kNaPad1 * 4);
+constexpr size_t kNaRescan = kNaSecond0 + align256((size_t)kNaPad0 * 4);
+constexpr size_t kNaSmall = kNaRescan + align256((size_t)2 * (kNaPad0 + kNaPad1) * 4);   // stats 16 B | dims 8 B | pad | rescan count 16 B
+constexpr size_t kNaBytes = kNaSmall + 256;
+
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char *g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each GPU, resolved once per device
+std::mutex g_scratch_mutex;
+
+// dims, zeroed rounding statistics of the pair
+__global__ void noalloc_setup_kernel(PairDims *dims, unsigned *stats, int n0, int n1)
+{
+    if (threadIdx.x == 0) { dims->n0 = n0; dims->n1 = n1; }
+    if (threadIdx.x < 4) stats[threadIdx.x] = 0u;
+}
+
+int device_pointer_check(const void *p, const char *what)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeUnregistered) {
+        (void)hipGetLastError();
+        set_error("%s must be a device pointer", what);
+        return VS_ERR_INVALID;
+    }
+    return VS_OK;
+}
+}  // namespace
+
+int vs_match_two_way_noalloc(const float *desc0, int32_t n0, const float *desc1, int32_t n1,
+                             float nn_thresh, float ratio, int32_t *out_i, int32_t *out_j,
+                             float *out_d, int32_t *out_n, void *hip_stream)
+{
+    VS_CHECK(out_n != nullptr, VS_ERR_INVALID, "null out_n");
+    VS_CHECK(n0 >= 0 && n1 >= 0, VS_ERR_INVALID, "negative size");
+    VS_CHECK(n0 <= kNoAllocMaxN && n1 <= kNoAllocMaxN, VS_ERR_INVALID,
+             "%d x %d descriptors exceed the allocation-free matcher's limit of %d per side", n0, n1, kNoAllocMaxN);
+    hipStream_t s = (hipStream_t)hip_stream;
+    VS_TRY(device_pointer_check(out_n, "out_n"));
+    if (n0 == 0 || n1 == 0) {            // the reference's loops do nothing on empty inputs
+        VS_HIP(hipMemsetAsync(out_n, 0, sizeof(int32_t), s));
+        return VS_OK;
+    }
+    VS_CHECK(desc0 && desc1 && out_i && out_j && out_d, VS_ERR_INVALID, "null argument");
+    VS_TRY(device_pointer_check(desc0, "desc0")); VS_TRY(device_pointer_check(desc1, "desc1"));
+    VS_TRY(device_pointer_check(out_i, "out_i")); VS_TRY(device_pointer_check(out_j, "out_j"));
+    VS_TRY(device_pointer_check(out_d, "out_d"));
+    int dev = 0;
+    VS_HIP(hipGetDevice(&dev));
+    VS_CHECK(dev >= 0 && dev < kMaxDevices, VS_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev, kMaxDevices);
+    unsigned char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {       // each GPU holds its own copy of the array at its own address
+            void *p = nullptr;
+            VS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[dev] = (unsigned char *)p;
+        }
+        base = g_scratch_ptr[dev];
+    }
+    MatchView v;
+    v.n0_pad = (n0 + kBM - 1) / kBM * kBM; v.n1_pad = (n1 + kBN - 1) / kBN * kBN;
+    v.d0 = desc0; v.d1 = desc1;
+    v.a16 = (_Float16 *)(base + kNaA16); v.b16 = (_Float16 *)(base + kNaB16);
+    v.row_part = (float2 *)(base + kNaRowPart); v.col_part = (float2 *)(base + kNaColPart);
+    v.idx0 = (int *)(base + kNaIdx0); v.idx1 = (int *)(base + kNaIdx1);
+    v.dist0 = (float *)(base + kNaDist0); v.dist1 = (float *)(base + kNaDist1);
+    v.second0 = (float *)(base + kNaSecond0);
+    v.rescan_list = (int *)(base + kNaRescan);
+    v.stats = (unsigned *)(base + kNaSmall); v.dims = (PairDims *)(base + kNaSmall + 16);
+    v.rescan_count = (int *)(base + kNaSmall + 64);
+    v.xy0 = v.xy1 = nullptr;
+    v.out_i = out_i; v.out_j = out_j; v.out_d = out_d; v.out_n = out_n;
+    hipLaunchKernelGGL(noalloc_setup_kernel, dim3(1), dim3(64), 0, s, v.dims, v.stats, n0, n1);
+    hipLaunchKernelGGL(split_kernel, dim3(div_up(v.n0_pad, kSplitRows)), dim3(256), 0, s, desc0, n0, v.n0_pad, v.a16, v.stats);
+    hipLaunchKernelGGL(split_kernel, dim3(div_up(v.n1_pad, kSplitRows)), dim3(256), 0, s, desc1, n1, v.n1_pad, v.b16, v.stats + 2);
+    VS_TRY(launch_ok("split_kernel"));
+    return run_match(v, 1, false, nn_thresh, ratio, s, nullptr);
 }
 
 }  // extern "C"

@@ -1,15 +1,19 @@
 """Benchmark of the MI355X hot path.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5shard]
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5shard|c5]
 
 A step = one pass of the fused residual + Jacobian + Schur linearisation (vs_ba_linearize) over
-one synthetic bundle-adjustment problem resident in HBM.  N = 1 times BASELINE.json configs[1]
-(50 keyframes, 20k landmarks, ~200k observations).  N > 1 (launched by torch.distributed.run, one
-rank per GPU) is weak scaling: N x 20k landmarks over the same 50 cameras, landmark shard r on
-rank r, and the reduced camera system summed across ranks by an RCCL all-reduce every step.
-Rank 0 prints ONE JSON line; `value` is observations/s over all ranks.  The same line carries
-`roofline` (HIP-event kernel times measured here), `cpu_baseline` (the CPU oracle timed on this
-host) and, in `extra`, the matcher leg (BASELINE.json configs[2]) and the larger BA shapes.
+one synthetic bundle-adjustment problem resident in HBM, followed for N > 1 by the all-reduce of
+the reduced camera system.  The default workload is BASELINE.json configs[3] (1k cameras, 500k
+landmarks, ~2M observations), the shape the metric's "1-8 GPU" part is quoted on: it fits one GPU
+and its landmarks shard over N GPUs, so every N runs the SAME problem (strong scaling): rank r
+linearises landmark shard r and the ranks sum their partial reduced systems with an RCCL
+all-reduce issued by the library on the step's own stream (vs_comm_allreduce_sum).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (one process per
+GPU, before anything touches a GPU here); under torch.distributed.run the ranks are taken from the
+environment.  Rank 0 prints ONE JSON line; `value` is observations/s over all ranks.  The line
+carries `roofline` (HIP-event kernel times measured here), `cpu_baseline` (the CPU oracle timed on
+this host) and, in `extra`, the matcher leg (configs[2]), configs[1] and the larger BA shapes.
 """
 import argparse
 import json
@@ -34,6 +38,16 @@ class _DevArray:
                                          "version": 2}
 
 
+def trace(msg):
+    """Progress lines on stderr when VS_BENCH_TRACE is set (stdout carries only the JSON line)."""
+    if os.environ.get("VS_BENCH_TRACE"):
+        sys.stderr.write("[bench rank %s +%.1fs] %s\n" % (os.environ.get("RANK", "0"), time.time() - _T0, msg))
+        sys.stderr.flush()
+
+
+_T0 = time.time()
+
+
 def fused_bytes(No, Np, Nc, nblocks):
     """Algorithmic bytes of one fused linearisation in the fp64 layout the kernels use:
     in : per observation camera index 4 + point index 4 + (u,v) 16; 24 per point; 48 per camera
@@ -45,13 +59,13 @@ def make_problem(name, rank, world, seed=0):
     from visual_slam_amd import synth
     from visual_slam_amd.ba import BAProblem
     Nc, Np, k, band = synth.BA_CONFIGS[name]
-    sc = synth.make_ba_scene(Nc, Np * world, k, band=band, seed=seed)
+    sc = synth.make_ba_scene(Nc, Np, k, band=band, seed=seed)
     ba = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=rank,
                                world=world)
     return sc, ba
 
 
-def bench_ba(args, rank, world, dist, torch):
+def bench_ba(args, rank, world, dist, torch, comm):
     t0 = time.time()
     sc, ba = make_problem(args.workload, rank, world)
     stream = torch.cuda.current_stream()
@@ -65,42 +79,61 @@ def bench_ba(args, rank, world, dist, torch):
     pp = C.cast(C.c_void_p(dp.data_ptr()), C.POINTER(C.c_double))
     assert lib.vs_ba_linearize(ba.h, pc, pp) == 0
     ptr, n = ba.reduce_buffer()
-    red = torch.as_tensor(_DevArray(ptr, n), device="cuda") if dist is not None else None
+    red = torch.as_tensor(_DevArray(ptr, n), device="cuda") if (dist is not None and comm is None) else None
     setup_s = time.time() - t0
+    sptr = C.c_void_p(stream.cuda_stream)
+    trace("problem ready (%.1f s)" % setup_s)
+
+    def allreduce():
+        if comm is not None:      # RCCL all-reduce enqueued by the library on the step's stream
+            rc = lib.vs_comm_allreduce_sum(comm, C.c_void_p(ptr), C.c_int64(n), sptr)
+            assert rc == 0
+        elif dist is not None:    # rehearsal backend (gloo): summed on the host, copied back
+            host = red.cpu()
+            dist.all_reduce(host)
+            red.copy_(host)
 
     def step():
         rc = lib.vs_ba_linearize(ba.h, pc, pp)
         assert rc == 0
-        if dist is not None:
-            dist.all_reduce(red)
+        allreduce()
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, reps):
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt], device="cuda" if comm is not None else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
-    sync()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t1
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    trace("warm-up done")
+    dt = timed(step, args.steps)
+    trace("timed region done")
+    allreduce_ms = None
+    if dist is not None:
+        allreduce_ms = timed(allreduce, max(10, args.steps // 10)) / max(10, args.steps // 10) * 1e3
     ms_per_step = dt / args.steps * 1e3
     total_obs = sc.No
     value = total_obs / (dt / args.steps)
     out = dict(ms_per_step=ms_per_step, value=value, setup_s=setup_s, No=int(sc.No), Np=int(sc.Np),
-               Nc=int(sc.Nc))
+               Nc=int(sc.Nc), allreduce_ms_per_step=allreduce_ms, allreduce_bytes=int(n) * 8)
     if rank == 0:
         ms = ba.profile_linearize(dc.cpu().numpy(), dp.cpu().numpy(), iters=max(20, args.steps // 2))
         br, _ = ba.block_index()
-        local_No = sc.No // world
-        alg = fused_bytes(local_No, sc.Np // world, sc.Nc, len(br))
+        # this rank's shard: its observations and landmarks, every camera and block
+        alg = fused_bytes(sc.No // world, sc.Np // world, sc.Nc, len(br))
         k_ms = kernel_times(ms)
         kern_sum = float(sum(k_ms.values()))
         dom = max(k_ms, key=k_ms.get)
@@ -223,7 +256,7 @@ def bench_match(args, rank, world, dist, torch, n=4096, total_pairs=64):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     per_batch = dt / steps
@@ -329,22 +362,44 @@ def cpu_baseline(name):
     return out
 
 
+def spawn_ranks(n):
+    """Starts n copies of this script, one rank per GPU, and returns the worst exit code.  Runs
+    before anything in this process touches a GPU; rank 0's stdout (the JSON line) passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    return max(abs(p.wait()) for p in procs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5shard", "c5"])
+    ap.add_argument("--workload", default="c4", choices=["c1", "c2", "c4", "c5shard", "c5"])
     ap.add_argument("--no-extra", action="store_true", help="skip the matcher leg and larger BA shapes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise a process group and all-reduce even with one rank (rehearsal of the N>1 path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # rehearsal of the N>1 path on a box with fewer GPUs than ranks: VS_BENCH_BACKEND=gloo lets the
@@ -354,8 +409,11 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
+    comm = None
     if world > 1 or args.force_dist:
+        import ctypes as C
         import torch.distributed as dist
+        from visual_slam_amd import _lib
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -369,14 +427,33 @@ def main():
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
             else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
-            warm = torch.zeros(8, device="cuda", dtype=torch.float64)
+            warm = torch.zeros(8, device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            if backend == "nccl":
+                # the library's own communicator: rank 0 makes the id, torch.distributed carries it
+                lib = _lib.load()
+                ident = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    buf = (C.c_char * 128)()
+                    _lib.check(lib.vs_comm_unique_id(buf))
+                    ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                ident = ident.cuda()
+                dist.broadcast(ident, 0)
+                raw = bytes(ident.cpu().numpy().tobytes())
+                comm = C.c_void_p()
+                _lib.check(lib.vs_comm_create(C.byref(comm), rank, world, raw))
+                x = torch.ones(8, device="cuda", dtype=torch.float64)
+                _lib.check(lib.vs_comm_allreduce_sum(comm, C.c_void_p(x.data_ptr()), C.c_int64(8), None))
+                torch.cuda.synchronize()
+                assert float(x[0].item()) == float(world)
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    ba = bench_ba(args, rank, world, dist, torch)
+    trace("process group ready" if dist is not None else "single rank")
+    ba = bench_ba(args, rank, world, dist, torch, comm)
+    trace("BA leg done")
     extra = {}
     if not args.no_extra:
         extra["matcher"] = bench_match(args, rank, world, dist, torch)
@@ -389,13 +466,17 @@ def main():
             "metric": "BA observations/sec (residual+J+Schur) & SuperPoint matches/sec, 1\u20138 GPU",
             "value": ba["value"], "unit": "observations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ba["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d cameras, %d landmarks, %d observations%s" % (
                 args.workload, ba["Nc"], ba["Np"], ba["No"],
-                "" if world == 1 else " (landmarks sharded over %d GPUs, RCCL all-reduce of the reduced camera system)" % world),
+                "" if world == 1 else " (landmarks sharded over %d GPUs, RCCL all-reduce of the reduced camera system every step)" % world),
                 "precision": "fp64 values, int32 indices"},
             "roofline": ba["roofline"],
         }
+        if world > 1 or args.force_dist:
+            line["allreduce"] = dict(ms_per_step=ba["allreduce_ms_per_step"], bytes=ba["allreduce_bytes"],
+                                     via="vs_comm_allreduce_sum (RCCL, library stream)" if comm is not None
+                                     else "torch.distributed " + backend)
         if "two_streams" in ba:
             extra["ba_two_streams"] = ba["two_streams"]
         if "matcher" in extra:   # second half of the metric: SuperPoint query rows matched per second
@@ -407,8 +488,12 @@ def main():
             line["cpu_baseline"] = None
         line["extra"] = extra
         print(json.dumps(line))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
+        if comm is not None:
+            from visual_slam_amd import _lib
+            _lib.load().vs_comm_destroy(comm)
         dist.destroy_process_group()
 
 

@@ -19,5 +19,8 @@ for p in range(pairs):
     d1 = (d1 / d1.norm(dim=1, keepdim=True)).contiguous()
     keep.append((d0, d1)); mt.set_pair(p, (d0.data_ptr(), n), (d1.data_ptr(), n))
 torch.cuda.synchronize()
+for _ in range(int(os.environ.get('VS_PROF_WARM', '100'))):
+    mt.run(pairs, 0.7)
+torch.cuda.synchronize()
 ms = mt.profile_run(pairs, 0.7, iters=iters)
 print('pairs', pairs, 'stages ms', [round(float(x), 3) for x in ms], 'rescans', mt.rescans())

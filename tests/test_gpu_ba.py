@@ -224,6 +224,24 @@ def test_wide_band_solver_matches_oracle_and_dense(orc, monkeypatch):
     monkeypatch.delenv("VS_BA_SOLVER")
 
 
+@pytest.mark.parametrize("Nc,Np,k,band,seed", [(200, 3000, 4, 8, 31), (333, 4000, 5, 20, 32), (70, 1500, 4, 16, 33),
+                                               (64, 1200, 4, 12, 34), (1000, 20000, 4, 16, 35)])
+def test_cyclic_reduction_matches_band_cholesky_and_oracle(orc, monkeypatch, Nc, Np, k, band, seed):
+    """Long camera chains are solved by block cyclic reduction (blocks of 16 or 32 cameras, chains
+    of 4 to 63 blocks, lengths that are and are not powers of two): same LM step as the sequential
+    band Cholesky and as the oracle's dense solve."""
+    sc = synth.make_ba_scene(Nc, Np, k, band=band, seed=seed)
+    ref, gpu = both(orc, sc)
+    d1, p1, m1 = gpu.lm_step(1e4)                    # default: cyclic reduction
+    monkeypatch.setenv("VS_BA_SOLVER", "band")
+    d2, p2, m2 = gpu.lm_step(1e4)
+    monkeypatch.delenv("VS_BA_SOLVER")
+    assert rel(d1, d2) < 1e-8 and rel(p1, p2) < 1e-8 and abs(m1 - m2) < 1e-9 * abs(m2)
+    if Nc <= 400:
+        rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+        assert rc == 0 and rel(d1, d0) < 1e-6 and rel(p1, p0) < 1e-6 and abs(m1 - m0) < 1e-8 * abs(m0)
+
+
 def test_sharded_partial_systems_sum_to_the_whole():
     sc = synth.make_ba_config("c1", seed=10)
     d = np.full(6 * sc.Nc, 0.3), np.full(3 * sc.Np, 0.3)

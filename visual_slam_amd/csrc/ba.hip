@@ -10,6 +10,7 @@
 #include "common.h"
 #include "ba_kernels.h"
 #include "dense_solve.h"
+#include "bcr_solve.h"
 
 using namespace vs;
 
@@ -108,7 +109,7 @@ struct vs_ba {
     DevBuf<unsigned char> cam_used, pt_used;
     DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
     DevBuf<real> scale_c, scale_p, lam_c, lam_c_user, lam_p_user, dcam, dpt, mcc_partial,
-        cand_partial, scalars, dense, linv;
+        cand_partial, scalars, dense, linv, bcr_ws;
     DevBuf<int> info;
 
     real *S_diag() { return red.p; }
@@ -575,6 +576,16 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         const int band = 6 * h->max_pair_gap + 5;
         bool banded = (int64_t)(band + 1) * 2 <= n;
         if (const char *e = getenv("VS_BA_SOLVER")) banded = banded && strcmp(e, "dense") != 0;   // test knob
+        // long chains of cameras: block cyclic reduction, parallel over the chain (bcr_solve.h)
+        const BcrPlan plan = banded ? bcr_plan(Nc, h->max_pair_gap) : BcrPlan();
+        bool use_bcr = plan.g > 0;
+        if (const char *e = getenv("VS_BA_SOLVER")) use_bcr = use_bcr && strcmp(e, "band") != 0 && strcmp(e, "dense") != 0;   // test knob
+        if (use_bcr) {
+            const size_t need = bcr_workspace_reals(plan);
+            if (h->bcr_ws.n < need) VS_TRY(h->bcr_ws.alloc(need));
+            VS_TRY(bcr_solve(plan, h->bcr_ws.p, Nc, h->nb_off, h->brow.p, h->bcol.p, h->S_diag(), h->S_off(), h->rhs(),
+                             h->dcam.p, h->info.p, s));
+        } else {
         const int bw = banded ? band : n;
         // Row stride padded to a multiple of 16 elements: with panels starting at multiples of 32,
         // every 16-element row segment of a 16 x 16 tile is then exactly one aligned 128-byte line
@@ -594,6 +605,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         const size_t linv_elems = (size_t)div_up(n, kNB) * kNB * kNB;
         if (h->linv.n < linv_elems) VS_TRY(h->linv.alloc(linv_elems));
         VS_TRY(cholesky_solve(A, h->dcam.p, n, ld, bw, h->info.p, h->linv.p, s));
+        }
     }
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)

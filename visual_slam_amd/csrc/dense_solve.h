@@ -423,8 +423,11 @@ constexpr int kCholThreads = 512, kCholWaves = kCholThreads / 64;   // 8 waves: 
 // The trailing window lives in L2; the block inverses are kept for the triangular solves.
 __global__ void __launch_bounds__(kCholThreads)
 chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restrict__ info,
-                   real *__restrict__ Linv, int buf_rows)
+                   real *__restrict__ Linv, int buf_rows, int64_t batch_stride_A, int64_t batch_stride_Linv)
 {
+    // batched use (one matrix per workgroup): matrix blockIdx.x lives batch_stride_A reals further
+    A += (int64_t)blockIdx.x * batch_stride_A;
+    Linv += (int64_t)blockIdx.x * batch_stride_Linv;
     __shared__ real Wn[kNB][kNB + 1];                            // diagonal block of the next panel
     __shared__ real Ld[kNB][kNB + 1];                            // Ld[c][i] = L[i][c] of the current block
     __shared__ __attribute__((aligned(16))) real wimg[48 * kSS];  // scratch of the factoring wave
@@ -1006,6 +1009,29 @@ __global__ void solve6_kernel(int Nc, const real *__restrict__ S_diag, const rea
     if (bad && *info == 0) *info = c + 1;
 }
 
+// Dynamic LDS beyond the default limit for the single-workgroup Cholesky kernels: a per-device
+// function attribute, set once per GPU.
+static inline int chol_window_raise_lds_limit()
+{
+    static std::mutex lds_mutex;
+    static bool lds_limit_raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return VS_ERR_HIP; }
+    std::lock_guard<std::mutex> lock(lds_mutex);
+    if (!lds_limit_raised[dev]) {
+        const int max_lds = kFusedMaxRows * kXS * (int)sizeof(real);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_window_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
+            set_error("cannot raise the dynamic LDS limit of the single-workgroup Cholesky kernels");
+            return VS_ERR_HIP;
+        }
+        lds_limit_raised[dev] = true;
+    }
+    return VS_OK;
+}
+
 // Factor + solve.  A, ld, bw: storage as described at the top of this file, lower triangle
 // filled; b: rhs, overwritten with the solution; info (device int, zeroed by the caller): first
 // failing pivot + 1, or 0; Linv: device workspace of ceil(n / 32) * 32 * 32 reals.  The storage behind A
@@ -1015,29 +1041,11 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
 {
     const int window = bw < n ? bw : n;
     if (window <= kFusedMaxRows) {
-        // dynamic LDS beyond the default limit: a per-device function attribute, set once per GPU
-        static std::mutex lds_mutex;
-        static bool lds_limit_raised[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return VS_ERR_HIP; }
-        {
-            std::lock_guard<std::mutex> lock(lds_mutex);
-            if (!lds_limit_raised[dev]) {
-                const int max_lds = kFusedMaxRows * kXS * (int)sizeof(real);
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_window_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
-                    set_error("cannot raise the dynamic LDS limit of the single-workgroup Cholesky kernels");
-                    return VS_ERR_HIP;
-                }
-                lds_limit_raised[dev] = true;
-            }
-        }
+        VS_TRY(chol_window_raise_lds_limit());
         const int buf_rows = (window + 15) & ~15;
         if (window <= kLookaheadMaxRows)
             hipLaunchKernelGGL(chol_window_kernel, dim3(1), dim3(kCholThreads), (size_t)2 * buf_rows * kXS * sizeof(real), s,
-                               A, n, ld, bw, info, Linv, buf_rows);
+                               A, n, ld, bw, info, Linv, buf_rows, (int64_t)0, (int64_t)0);
         else
             hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(kCholThreads), (size_t)buf_rows * kXS * sizeof(real), s,
                                A, n, ld, bw, info, Linv);

@@ -266,6 +266,18 @@ def bench_match(args, rank, world, dist, torch, n=4096, total_pairs=64):
         ms = mt.profile_run(pairs, 0.7, iters=3)
         flops = 2.0 * n * n * 256 * pairs
         ach = flops / (float(ms[0]) * 1e-3) / 1e12
+        # the same batch with the ratio test on (BASELINE config 3: "ratio + mutual check")
+        for _ in range(2):
+            mt.run(pairs, 0.7, 0.8)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for _ in range(steps):
+            mt.run(pairs, 0.7, 0.8)
+        torch.cuda.synchronize()
+        per_ratio = (time.perf_counter() - t4) / steps
+        out["ratio_on"] = dict(ratio=0.8, ms_per_batch=per_ratio * 1e3, query_rows_per_s=pairs * n / per_ratio,
+                               matches_pair0=len(mt.matches(0)[0]), slowdown_vs_ratio_off=per_ratio / per_batch)
+        mt.run(pairs, 0.7)
         out["rescans_per_pair"] = mt.rescans() / pairs
         n_match = len(mt.matches(0)[0])
         out["matches_pair0"] = n_match

@@ -172,3 +172,19 @@ def test_full_size_pair_with_ratio_test(orc):
         same(got, orc.two_way_matching(d0, d1, th, ratio))
     plain = vm.two_way(d0, d1, 0.7, 1.0)
     assert 0 < len(got[0]) and len(vm.two_way(d0, d1, 0.7, 0.8)[0]) <= len(plain[0])
+
+
+def test_ratio_test_with_stereo_mask_ties_and_tiny_sets(orc):
+    """Ratio test where the second best is ambiguous by construction: masked stereo entries all tie
+    at distance 1.0, duplicated columns tie with the best, and a single column has no second."""
+    d0, d1 = synth.make_descriptors(300, 280, seed=44, duplicates=3)
+    xy0, xy1 = synth.make_keypoints(300, seed=3), synth.make_keypoints(280, seed=53)
+    for ratio in (0.9, 0.99):
+        same(vm.stereo(d0, xy0, d1, xy1, 2.0, ratio), orc.stereo_matching(d0, xy0, d1, xy1, 2.0, ratio))
+    d1b = d1.copy()
+    d1b[7] = d1b[8] = d1b[9]                                    # best and second equal for some rows
+    same(vm.two_way(d0, d1b, 2.0, 0.8), orc.two_way_matching(d0, d1b, 2.0, 0.8))
+    e0, e1 = synth.make_descriptors(5, 1, seed=2)
+    same(vm.two_way(e0, e1, 2.0, 0.8), orc.two_way_matching(e0, e1, 2.0, 0.8))
+    f0, f1 = synth.make_descriptors(130, 2, seed=3)
+    same(vm.two_way(f0, f1, 2.0, 0.8), orc.two_way_matching(f0, f1, 2.0, 0.8))

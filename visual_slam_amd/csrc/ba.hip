@@ -90,6 +90,8 @@ struct vs_ba {
     vs_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
     vs_comm *comm = nullptr;
+    const void *known_dev_dc = nullptr, *known_dev_dp = nullptr;   // damping pointers already classified as device memory
+    DevBuf<real> eval_res, eval_Jc, eval_Jp;                       // staging of vs_ba_evaluate, grown on demand
     int pt_lo = 0, pt_hi = 0;   // landmarks this handle linearises
     DevBuf<real> rank_slots;    // one value per rank: maxima through a sum-only collective
 
@@ -420,7 +422,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
 
 // Linearise at parameters (t,rpy,pts on device) and form the undamped-camera reduced system in
 // h->red.  Point damping is applied inside (it is local to a landmark); camera damping later.
-int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDamping pd)
+int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDamping pd, const real *lam_c = nullptr)
 {
     auto mark = [&](int i) { if (h->prof_ev) (void)hipEventRecord(h->prof_ev[i], h->stream); };
     mark(0);
@@ -454,12 +456,12 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                 hipLaunchKernelGGL((blocks_kernel<4, kEpt4>), dim3(n_items), dim3(4 * kWave), 0, h->stream, n_items, list,
                                    h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
-                                   h->Nc, h->nb_off, h->cost_partial.p, h->n_lm4_blocks);
+                                   h->Nc, h->nb_off, h->cost_partial.p, h->n_lm4_blocks, lam_c);
             else
                 hipLaunchKernelGGL((blocks_kernel<1, kEpt1>), dim3(n_items), dim3(kWave), 0, h->stream, n_items, list,
                                    h->K, h->cams.p, h->lmrec.p, h->cpt.p, h->cuv.p, h->bent.p, h->hub,
                                    h->hub_w.p, (int)h->fix_points, h->diag_partial.p, h->off_partial.p, h->red.p,
-                                   h->Nc, h->nb_off, h->cost_partial.p, h->n_lm4_blocks);
+                                   h->Nc, h->nb_off, h->cost_partial.p, h->n_lm4_blocks, lam_c);
             VS_TRY(launch_check("blocks_kernel"));
         }
         if (!h->fix_points && h->n_small16 > 0) {
@@ -489,7 +491,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
         const int64_t n_fin = (int64_t)h->Nc * kDiagVals + (int64_t)nb_fin * kOffVals;
         hipLaunchKernelGGL(finalize_kernel, dim3(div_up(n_fin, 256) + 1), dim3(256), 0, h->stream, h->Nc, h->nb_off, nb_fin,
                            h->ditem_ptr.p, h->diag_partial.p, h->oitem_ptr.p, h->off_partial.p,
-                           n_items_run == 0 ? h->n_lm4_blocks : -1, h->cost_partial.p, h->red.p);
+                           n_items_run == 0 ? h->n_lm4_blocks : -1, h->cost_partial.p, h->red.p, lam_c);
         VS_TRY(launch_check("finalize_kernel"));
     }
     mark(5);
@@ -776,10 +778,13 @@ int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double
     hipStream_t s = h->stream;
     VS_TRY(prep_cameras(h, h->t.p, h->rpy.p));
     const int64_t Ng = h->No_global;
-    DevBuf<real> dres, dJc, dJp;
-    if (res) { VS_TRY(dres.alloc(2 * (size_t)Ng)); VS_HIP(hipMemsetAsync(dres.p, 0, 2 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
-    if (Jc) { VS_TRY(dJc.alloc(12 * (size_t)Ng)); VS_HIP(hipMemsetAsync(dJc.p, 0, 12 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
-    if (Jp) { VS_TRY(dJp.alloc(6 * (size_t)Ng)); VS_HIP(hipMemsetAsync(dJp.p, 0, 6 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
+    DevBuf<real> &dres = h->eval_res, &dJc = h->eval_Jc, &dJp = h->eval_Jp;
+    if (res && dres.n < 2 * (size_t)Ng) VS_TRY(dres.alloc(2 * (size_t)Ng));
+    if (Jc && dJc.n < 12 * (size_t)Ng) VS_TRY(dJc.alloc(12 * (size_t)Ng));
+    if (Jp && dJp.n < 6 * (size_t)Ng) VS_TRY(dJp.alloc(6 * (size_t)Ng));
+    if (res) { VS_HIP(hipMemsetAsync(dres.p, 0, 2 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
+    if (Jc) { VS_HIP(hipMemsetAsync(dJc.p, 0, 12 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
+    if (Jp) { VS_HIP(hipMemsetAsync(dJp.p, 0, 6 * (size_t)std::max<int64_t>(Ng, 1) * sizeof(real), s)); }
     if ((res || Jc || Jp) && h->No > 0) {
         hipLaunchKernelGGL(obs_jacobian_kernel, dim3(div_up(h->No, 256)), dim3(256), 0, s, h->No, h->K, h->cams.p,
                            h->pts.p, h->lcam.p, h->lpt.p, h->luv.p, h->lobs.p, h->hub,
@@ -807,13 +812,15 @@ int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double
 
 // Device pointers are used in place; host pointers are uploaded first.
 static int resident_or_upload(const double *src, size_t n, DevBuf<real> &stage, hipStream_t s,
-                              const real **out)
+                              const real **out, const void **known_device)
 {
     *out = nullptr;
     if (!src) return VS_OK;
+    if (src == *known_device) { *out = src; return VS_OK; }   // classified by an earlier call
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeDevice) {
         *out = src;
+        *known_device = src;
         return VS_OK;
     }
     (void)hipGetLastError();   // an unregistered host pointer reports an error: not a failure
@@ -828,16 +835,11 @@ int vs_ba_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p)
     hipStream_t s = h->stream;
     PointDamping pd{ nullptr, nullptr, 1.0, 0.0, 0.0 };
     const real *lc = nullptr;
-    VS_TRY(resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, s, &pd.lam_p));
-    VS_TRY(resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, s, &lc));
-    VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
-    if (lc) {
-        hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * h->Nc, 256)), dim3(256), 0, s, h->Nc, h->udiag(),
-                           (const real *)nullptr, lc, real(1), real(0), real(0), (real *)nullptr, h->S_diag(),
-                           (const real *)nullptr, (real *)nullptr, (int *)nullptr);
-        VS_TRY(launch_check("camera_damping_kernel"));
-    }
-    return VS_OK;
+    VS_TRY(resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, s, &pd.lam_p, &h->known_dev_dp));
+    VS_TRY(resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, s, &lc, &h->known_dev_dc));
+    // the camera damping is added as the diagonal blocks are stored (no extra pass); of the shards
+    // of a multi-GPU problem only rank 0 adds it, so that the cross-GPU sum carries it once
+    return linearize(h, h->t.p, h->rpy.p, h->pts.p, pd, h->rank == 0 ? lc : nullptr);
 }
 
 int vs_ba_profile_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p,
@@ -851,11 +853,11 @@ int vs_ba_profile_linearize(vs_ba_handle h, const double *damp_c, const double *
     int rc = vs_ba_linearize(h, damp_c, damp_p);   // warm-up
     PointDamping pd{ nullptr, nullptr, 1.0, 0.0, 0.0 };
     const real *lc = nullptr;
-    if (rc == VS_OK) rc = resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, h->stream, &pd.lam_p);
-    if (rc == VS_OK) rc = resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, h->stream, &lc);
+    if (rc == VS_OK) rc = resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, h->stream, &pd.lam_p, &h->known_dev_dp);
+    if (rc == VS_OK) rc = resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, h->stream, &lc, &h->known_dev_dc);
     for (int it = 0; it < iters && rc == VS_OK; it++) {
         h->prof_ev = ev;
-        rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, pd);
+        rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, pd, h->rank == 0 ? lc : nullptr);
         h->prof_ev = nullptr;
         if (rc != VS_OK) break;
         if (hipEventSynchronize(ev[5]) != hipSuccess) { set_error("event sync failed"); rc = VS_ERR_HIP; break; }

@@ -495,6 +495,7 @@ __device__ __forceinline__ void clear_reduce_pads(real *lds_wave, int lane, int 
 //   [ S_diag Nc x 36 | S_off nb_off x 36 | rhs 6Nc | diag(U) 6Nc | g_c 6Nc | cost ].
 struct RedView {
     real *S_diag, *S_off, *rhs, *udiag, *gc, *cost;
+    const real *lam_c;     // optional camera damping (6 Nc) added to the diagonal of S_cc as it is stored
 };
 __host__ __device__ __forceinline__ RedView red_view(real *red, int Nc, int nb_off)
 {
@@ -505,6 +506,7 @@ __host__ __device__ __forceinline__ RedView red_view(real *red, int Nc, int nb_o
     r.udiag = r.rhs + 6 * (int64_t)Nc;
     r.gc = r.udiag + 6 * (int64_t)Nc;
     r.cost = r.gc + 6 * (int64_t)Nc;
+    r.lam_c = nullptr;
     return r;
 }
 
@@ -516,6 +518,7 @@ __device__ __forceinline__ void store_diag_value(const RedView &rv, int c, int v
         int p = 0, rem = v;
         while (rem >= 6 - p) { rem -= 6 - p; p++; }
         const int q = p + rem;
+        if (p == q && rv.lam_c) s += rv.lam_c[6 * c + p];
         rv.S_diag[(int64_t)c * 36 + 6 * p + q] = s;
         rv.S_diag[(int64_t)c * 36 + 6 * q + p] = s;
     } else if (v < 27) rv.rhs[6 * c + v - 21] = s;
@@ -580,7 +583,8 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
               const int *__restrict__ cpt, const real *__restrict__ cuv,
               const int *__restrict__ bent, HuberObs hub, const real *__restrict__ hub_w,
               int fix_points, real *__restrict__ diag_partial, real *__restrict__ off_partial,
-              real *red, int Nc, int nb_off, const real *__restrict__ cost_partial, int n_cost_partials)
+              real *red, int Nc, int nb_off, const real *__restrict__ cost_partial, int n_cost_partials,
+              const real *__restrict__ lam_c)
 {
     __shared__ real lds[WAVES * 21 * kRedStride + WAVES * 24];
     const int lane = threadIdx.x & 63;
@@ -597,7 +601,8 @@ blocks_kernel(int n_items, const BlockItem *__restrict__ items, Intr K,
         item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
     }
     const BlockItem it = items[item];
-    const RedView rv = red_view(red, Nc, nb_off);
+    RedView rv = red_view(red, Nc, nb_off);
+    rv.lam_c = lam_c;
     if (blockIdx.x == 0) {
         // total cost = fixed-order sum of the landmark kernel's per-workgroup partials
         real c = real(0);
@@ -889,10 +894,11 @@ __global__ void __launch_bounds__(256)
 finalize_kernel(int Nc, int nb_off, int nb_sum, const int *__restrict__ diag_item_ptr,
                 const real *__restrict__ diag_partial, const int *__restrict__ off_item_ptr,
                 const real *__restrict__ off_partial, int n_cost_partials,
-                const real *__restrict__ cost_partial, real *__restrict__ red)
+                const real *__restrict__ cost_partial, real *__restrict__ red, const real *__restrict__ lam_c)
 {
     __shared__ real scratch[4];
-    const RedView rv = red_view(red, Nc, nb_off);
+    RedView rv = red_view(red, Nc, nb_off);
+    rv.lam_c = lam_c;
     if (blockIdx.x == gridDim.x - 1) {                 // last workgroup: cost (when asked to)
         if (n_cost_partials < 0) return;
         real s = real(0);

@@ -505,13 +505,31 @@ __device__ __forceinline__ ItemView item_view(int pair, int it, PairDims d, int 
     return v;
 }
 
+// Largest three of a stream of (value, chunk, is-a-chunk-best) entries.
+struct Top3 {
+    float v[3];
+    int tag[3];          // 2 * chunk + (1 if the value is its chunk's best)
+};
+__device__ __forceinline__ void top3_insert(Top3 &t, float x, int tag)
+{
+    if (x > t.v[0]) { t.v[2] = t.v[1]; t.tag[2] = t.tag[1]; t.v[1] = t.v[0]; t.tag[1] = t.tag[0]; t.v[0] = x; t.tag[0] = tag; }
+    else if (x > t.v[1]) { t.v[2] = t.v[1]; t.tag[2] = t.tag[1]; t.v[1] = x; t.tag[1] = tag; }
+    else if (x > t.v[2]) { t.v[2] = x; t.tag[2] = tag; }
+}
+
 // Merge the per-64 partials of every row and column; store the approximate winner and list the
-// items whose winner is not certain (all rows when force_rows is set).  One thread per item.
+// items whose winner is not certain.  One thread per item.
+// With want_second (the ratio test is on) every ROW also gets the column of its second-best score
+// where that is beyond doubt: the best and the second come from different chunks (so the second is
+// a chunk's best and its column is known), and both the best and the third lie more than the band
+// away from it (every score outside the partials is below its chunk's second, hence below the
+// third).  Other rows get -1 and are listed for the exact second-best scan.
 __global__ void __launch_bounds__(256)
 merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
              const float2 *__restrict__ row_part, const float2 *__restrict__ col_part,
              const unsigned *__restrict__ stats, int *__restrict__ idx0, int *__restrict__ idx1,
-             int *__restrict__ rescan_list, int *__restrict__ rescan_count, int force_rows)
+             int *__restrict__ rescan_list, int *__restrict__ rescan_count, int want_second,
+             int *__restrict__ sec_idx, int *__restrict__ sec_list)
 {
     const int pair = blockIdx.y;
     const int it = blockIdx.x * 256 + threadIdx.x;
@@ -522,6 +540,10 @@ merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
     float b1 = kNegInf, b2 = kNegInf;
     int pbest = 0;
     const int parts = (v.n_cand + kSub - 1) / kSub;
+    const bool second = want_second && v.is_row;
+    Top3 t3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { t3.v[k] = kNegInf; t3.tag[k] = -1; }
     int p = 0;
     for (; p + 8 <= parts; p += 8) {                  // eight loads in flight per thread
         float2 q[8];
@@ -531,21 +553,34 @@ merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
         for (int u = 0; u < 8; u++) {
             if (q[u].x > b1) pbest = p + u;
             top2_union(b1, b2, q[u].x, q[u].y);
+            if (second) { top3_insert(t3, q[u].x, 2 * (p + u) + 1); top3_insert(t3, q[u].y, 2 * (p + u)); }
         }
     }
     for (; p < parts; p++) {
         const float2 q = v.part[p * v.stride];
         if (q.x > b1) pbest = p;
         top2_union(b1, b2, q.x, q.y);
+        if (second) { top3_insert(t3, q.x, 2 * p + 1); top3_insert(t3, q.y, 2 * p); }
     }
     const int win = parts > 0 ? partial_index(v.is_row, pbest, b1) : -1;
     if (v.is_row) idx0[(int64_t)pair * n0_pad + v.self] = win;
     else idx1[(int64_t)pair * n1_pad + v.self] = win;
-    const bool uncertain = (force_rows && v.is_row) || !(clamp_score(b1) - clamp_score(b2) > pair_band(stats, pair));
+    const float band = pair_band(stats, pair);
+    const bool uncertain = !(clamp_score(b1) - clamp_score(b2) > band);
     if (uncertain && parts > 0) {
         const int slot = atomicAdd(rescan_count, 1);
         rescan_list[2 * (int64_t)slot] = pair;
         rescan_list[2 * (int64_t)slot + 1] = it;
+    }
+    if (second) {
+        const bool plain = !uncertain && (t3.tag[1] & 1) && (t3.tag[1] >> 1) != (t3.tag[0] >> 1) &&
+                           clamp_score(t3.v[1]) - clamp_score(t3.v[2]) > band;
+        sec_idx[(int64_t)pair * n0_pad + v.self] = plain ? partial_index(true, t3.tag[1] >> 1, t3.v[1]) : -1;
+        if (!plain) {
+            const int slot = atomicAdd(rescan_count + 1, 1);
+            sec_list[2 * (int64_t)slot] = pair;
+            sec_list[2 * (int64_t)slot + 1] = v.self;
+        }
     }
 }
 
@@ -657,7 +692,7 @@ mutual_distance_kernel(const float *__restrict__ d0, const float *__restrict__ d
                        const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
                        const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
                        const int *__restrict__ idx0, const int *__restrict__ idx1,
-                       float *__restrict__ dist0)
+                       float *__restrict__ dist0, const int *__restrict__ sec_idx, float *__restrict__ second0)
 {
     __shared__ __attribute__((aligned(16))) float tA[64 * kPanelStride];
     __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
@@ -682,60 +717,107 @@ mutual_distance_kernel(const float *__restrict__ d0, const float *__restrict__ d
     __syncthreads();
     const double acc = panel_dot64<false>(pA, pB, tA, tB, lane);
     if (i < n0) dist0[(int64_t)pair * n0_pad + i] = !mutual ? 3.0e38f : masked ? 1.0f : distance_from_dot(acc);
+    if (sec_idx == nullptr) return;
+    // ratio test: exact distance of the second-best column of the mutual rows that have one on record
+    int j2 = -1;
+    if (mutual) j2 = sec_idx[(int64_t)pair * n0_pad + i];
+    if (!__ballot(j2 >= 0)) return;
+    bool masked2 = false;
+    if (MASKED && j2 >= 0) masked2 = stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j2]);
+    __syncthreads();
+    pB[lane] = d1 + ((int64_t)pair * n1_pad + (j2 >= 0 ? j2 : 0)) * kD;
+    __syncthreads();
+    const double acc2 = panel_dot64<false>(pA, pB, tA, tB, lane);
+    if (j2 >= 0) second0[(int64_t)pair * n0_pad + i] = masked2 ? 1.0f : distance_from_dot(acc2);
 }
 
-// Ratio-test mode only: exact scan of one whole row or column per wave (first minimum) that
-// also yields the exact second-smallest distance of rows.
+// Ratio test, rows without a second-best column on record: exact second-smallest distance of the
+// row, one wave per listed row (mutual rows only: the others never reach the output).  Every
+// column whose approximate score lies within the band of the row's approximate second best can be
+// the exact second; chunks are pruned as in rescan_items_kernel, the row's exact nearest
+// neighbour (idx0) is left out, and the smallest remaining exact distance is the second.
 template <bool MASKED>
-__global__ void __launch_bounds__(256)
-rescan_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
-              const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
-              const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
-              const int *__restrict__ rescan_list, const int *__restrict__ rescan_count,
-              int *__restrict__ idx0, int *__restrict__ idx1, float *__restrict__ dist0,
-              float *__restrict__ dist1, float *__restrict__ second0)
+__global__ void __launch_bounds__(64)
+second_scan_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+                   const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
+                   const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
+                   const int *__restrict__ sec_list, const int *__restrict__ sec_count,
+                   const float2 *__restrict__ row_part, const float2 *__restrict__ col_part,
+                   const unsigned *__restrict__ stats, const int *__restrict__ idx0,
+                   const int *__restrict__ idx1, float *__restrict__ second0)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * 4;
-    const int count = *rescan_count;
-    for (int w = wave_global; w < count; w += n_waves) {
-        const int pair = rescan_list[2 * (int64_t)w], it = rescan_list[2 * (int64_t)w + 1];
-        const int n0 = dims[pair].n0, n1 = dims[pair].n1;
-        const bool is_row = it < n0_pad;
-        const int self = is_row ? it : it - n0_pad;
-        const int n_cand = is_row ? n1 : n0;
-        const float *base_self = is_row ? d0 + ((int64_t)pair * n0_pad + self) * kD
-                                        : d1 + ((int64_t)pair * n1_pad + self) * kD;
-        float bd = 3.0e38f, sd = 3.0e38f;
-        int bi = 0x7fffffff;
-        for (int c = lane; c < n_cand; c += 64) {
-            float d;
-            const int i = is_row ? self : c, j = is_row ? c : self;
-            if (MASKED && stereo_masked(xy0[(int64_t)pair * n0_pad + i], xy1[(int64_t)pair * n1_pad + j])) d = 1.0f;
-            else {
-                const float *other = is_row ? d1 + ((int64_t)pair * n1_pad + c) * kD
-                                            : d0 + ((int64_t)pair * n0_pad + c) * kD;
-                d = is_row ? exact_distance(base_self, other) : exact_distance(other, base_self);
+    __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
+    __shared__ __attribute__((aligned(16))) float tA[kD];
+    __shared__ const float *pA[1];
+    __shared__ const float *pB[64];
+    const int lane = threadIdx.x;
+    const int count = *sec_count;
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int pair = sec_list[2 * (int64_t)w], i = sec_list[2 * (int64_t)w + 1];
+        const PairDims dm = dims[pair];
+        const int jbest = idx0[(int64_t)pair * n0_pad + i];
+        if (jbest < 0 || jbest >= dm.n1 || idx1[(int64_t)pair * n1_pad + jbest] != i) continue;   // not mutual (uniform)
+        const ItemView v = item_view(pair, i, dm, n0_pad, n1_pad, row_part, col_part);
+        const int parts = (v.n_cand + kSub - 1) / kSub;
+        const float band = pair_band(stats, pair);
+        const float *self_row = d0 + ((int64_t)pair * n0_pad + i) * kD;
+        const float *other_base = d1 + (int64_t)pair * n1_pad * kD;
+        const int2 self_xy = MASKED ? xy0[(int64_t)pair * n0_pad + i] : make_int2(0, 0);
+        const int2 *other_xy = xy1 + (int64_t)pair * n1_pad;
+        // approximate second best of the row: the largest two of all partial values
+        float t1 = kNegInf, t2 = kNegInf;
+        for (int p = lane; p < parts; p += 64) { const float2 q = v.part[p * v.stride]; top2_union(t1, t2, q.x, q.y); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) top2_union(t1, t2, __shfl_xor(t1, off, 64), __shfl_xor(t2, off, 64));
+        const float second_approx = clamp_score(t2);
+        unsigned long long key = ~0ull;
+        auto candidate_key = [&](int c, double acc) -> unsigned long long {
+            float d = distance_from_dot(acc);
+            if (MASKED && stereo_masked(self_xy, other_xy[c])) d = 1.0f;
+            return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)c;
+        };
+        for (int pbase = 0; pbase < parts; pbase += 64) {
+            const int p = pbase + lane;
+            float2 q = make_float2(kNegInf, kNegInf);
+            if (p < parts) q = v.part[p * v.stride];
+            const bool in_band = p < parts && second_approx - clamp_score(q.x) <= band;
+            const bool whole = in_band && second_approx - clamp_score(q.y) <= band;
+            const bool single = in_band && !whole;
+            if (__ballot(single)) {
+                const int c = single ? partial_index(true, p, q.x) : 0;
+                __syncthreads();
+                if (lane == 0) pA[0] = self_row;
+                pB[lane] = other_base + (int64_t)c * kD;
+                __syncthreads();
+                const double acc = panel_dot64<true>(pA, pB, tA, tB, lane);
+                if (single && c != jbest) {
+                    const unsigned long long k = candidate_key(c, acc);
+                    key = k < key ? k : key;
+                }
             }
-            if (d < bd) { sd = bd; bd = d; bi = c; }
-            else if (d < sd) sd = d;
+            unsigned long long todo = __ballot(whole);
+            while (todo) {
+                const int pl = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int c = (pbase + pl) * kSub + lane;
+                const int cc = c < v.n_cand ? c : 0;
+                __syncthreads();
+                if (lane == 0) pA[0] = self_row;
+                pB[lane] = other_base + (int64_t)cc * kD;
+                __syncthreads();
+                const double acc = panel_dot64<true>(pA, pB, tA, tB, lane);
+                if (c < v.n_cand && c != jbest) {
+                    const unsigned long long k = candidate_key(c, acc);
+                    key = k < key ? k : key;
+                }
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float od = __shfl_xor(bd, off, 64), os = __shfl_xor(sd, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (od < bd || (od == bd && oi < bi)) { sd = fminf(bd, os); bd = od; bi = oi; }
-            else sd = fminf(sd, od);
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o < key ? o : key;
         }
-        if (lane == 0) {
-            if (is_row) {
-                idx0[(int64_t)pair * n0_pad + self] = bi; dist0[(int64_t)pair * n0_pad + self] = bd;
-                second0[(int64_t)pair * n0_pad + self] = sd;
-            } else {
-                idx1[(int64_t)pair * n1_pad + self] = bi; dist1[(int64_t)pair * n1_pad + self] = bd;
-            }
-        }
+        if (lane == 0) second0[(int64_t)pair * n0_pad + i] = key == ~0ull ? INFINITY : __uint_as_float((unsigned)(key >> 32));
     }
 }
 
@@ -809,6 +891,7 @@ struct vs_matcher {
     DevBuf<float2> row_part, col_part;   // (best, second) packed scores per item and 64-chunk
     DevBuf<float> dist0, dist1, second0, out_d;
     DevBuf<int> idx0, idx1, rescan_list, rescan_count, out_i, out_j, out_n;
+    DevBuf<int> sec_idx, sec_list;      // ratio test: second-best column per row, rows that need the exact scan
 };
 
 extern "C" {
@@ -835,7 +918,7 @@ int vs_matcher_create(vs_matcher_handle *out, int32_t max_pairs, int32_t max_n0,
     const size_t rp = P * (r1 / kSub) * r0, cp = P * (r0 / kSub) * r1;
     A(m->row_part.alloc(rp)); A(m->col_part.alloc(cp));
     A(m->idx0.alloc(P * r0)); A(m->idx1.alloc(P * r1)); A(m->dist0.alloc(P * r0)); A(m->dist1.alloc(P * r1));
-    A(m->second0.alloc(P * r0));
+    A(m->second0.alloc(P * r0)); A(m->sec_idx.alloc(P * r0)); A(m->sec_list.alloc(2 * P * r0));
     A(m->rescan_list.alloc(2 * P * (r0 + r1))); A(m->rescan_count.alloc(4));
     A(m->out_i.alloc(P * r0)); A(m->out_j.alloc(P * r0)); A(m->out_d.alloc(P * r0)); A(m->out_n.alloc(P));
     if (rc != VS_OK) { delete m; return rc; }
@@ -900,7 +983,8 @@ struct MatchView {
     PairDims *dims;
     float2 *row_part, *col_part;     // (best, second) packed scores per item and 64-chunk
     float *dist0, *dist1, *second0;
-    int *idx0, *idx1, *rescan_list, *rescan_count;
+    int *idx0, *idx1, *rescan_list, *rescan_count;   // rescan_count: [0] uncertain items, [1] rows for the exact second-best scan
+    int *sec_idx, *sec_list;
     int *out_i, *out_j, *out_n;
     float *out_d;
 };
@@ -928,37 +1012,36 @@ static int run_match(const MatchView &v, int n_pairs, bool masked, float nn_thre
                            v.xy1, r0, r1, tiles_per_wg, v.row_part, v.col_part);
     VS_TRY(launch_ok("dot_top2_kernel"));
     mark(1);
-    const int force = ratio < 1.0f ? 1 : 0;   // the ratio test needs every row's exact second best
+    const int want_second = ratio < 1.0f ? 1 : 0;     // the ratio test needs the exact second-smallest distance of the output rows
     VS_HIP(hipMemsetAsync(v.rescan_count, 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0 + r1, 256), n_pairs), dim3(256), 0, s, v.dims, r0, r1,
                        v.row_part, v.col_part, v.stats, v.idx0, v.idx1, v.rescan_list,
-                       v.rescan_count, force);
+                       v.rescan_count, want_second, v.sec_idx, v.sec_list);
     VS_TRY(launch_ok("merge_kernel"));
     mark(2);
-    if (force) {
-        // ratio test: every row needs its exact second-best distance -> whole-row scans
-        if (masked)
-            hipLaunchKernelGGL(rescan_kernel<true>, dim3(2048), dim3(256), 0, s, v.d0, v.d1, v.dims, v.xy0,
-                               v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.idx0, v.idx1,
-                               v.dist0, v.dist1, v.second0);
-        else
-            hipLaunchKernelGGL(rescan_kernel<false>, dim3(2048), dim3(256), 0, s, v.d0, v.d1, v.dims, v.xy0,
-                               v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.idx0, v.idx1,
-                               v.dist0, v.dist1, v.second0);
-    } else {
+    {
         const dim3 dgrid(div_up(r0, 64), n_pairs);
+        const int *sec = want_second ? v.sec_idx : nullptr;
         if (masked) {
             hipLaunchKernelGGL(rescan_items_kernel<true>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
                                v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
                                v.col_part, v.stats, v.idx0, v.idx1);
             hipLaunchKernelGGL(mutual_distance_kernel<true>, dgrid, dim3(64), 0, s, v.d0, v.d1, v.dims,
-                               v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0);
+                               v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0, sec, v.second0);
+            if (want_second)
+                hipLaunchKernelGGL(second_scan_kernel<true>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims, v.xy0, v.xy1,
+                                   r0, r1, v.sec_list, v.rescan_count + 1, v.row_part, v.col_part, v.stats, v.idx0,
+                                   v.idx1, v.second0);
         } else {
             hipLaunchKernelGGL(rescan_items_kernel<false>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
                                v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
                                v.col_part, v.stats, v.idx0, v.idx1);
             hipLaunchKernelGGL(mutual_distance_kernel<false>, dgrid, dim3(64), 0, s, v.d0, v.d1, v.dims,
-                               v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0);
+                               v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0, sec, v.second0);
+            if (want_second)
+                hipLaunchKernelGGL(second_scan_kernel<false>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims, v.xy0, v.xy1,
+                                   r0, r1, v.sec_list, v.rescan_count + 1, v.row_part, v.col_part, v.stats, v.idx0,
+                                   v.idx1, v.second0);
         }
     }
     VS_TRY(launch_ok("exact kernels"));
@@ -979,6 +1062,7 @@ static MatchView handle_view(vs_matcher *m)
     v.row_part = m->row_part.p; v.col_part = m->col_part.p;
     v.dist0 = m->dist0.p; v.dist1 = m->dist1.p; v.second0 = m->second0.p;
     v.idx0 = m->idx0.p; v.idx1 = m->idx1.p; v.rescan_list = m->rescan_list.p; v.rescan_count = m->rescan_count.p;
+    v.sec_idx = m->sec_idx.p; v.sec_list = m->sec_list.p;
     v.out_i = m->out_i.p; v.out_j = m->out_j.p; v.out_n = m->out_n.p; v.out_d = m->out_d.p;
     return v;
 }
@@ -1118,7 +1202,9 @@ constexpr size_t kNaDist0 = kNaIdx1 + align256((size_t)kNaPad1 * 4);
 constexpr size_t kNaDist1 = kNaDist0 + align256((size_t)kNaPad0 * 4);
 constexpr size_t kNaSecond0 = kNaDist1 + align256((size_t)kNaPad1 * 4);
 constexpr size_t kNaRescan = kNaSecond0 + align256((size_t)kNaPad0 * 4);
-constexpr size_t kNaSmall = kNaRescan + align256((size_t)2 * (kNaPad0 + kNaPad1) * 4);   // stats 16 B | dims 8 B | pad | rescan count 16 B
+constexpr size_t kNaSecIdx = kNaRescan + align256((size_t)2 * (kNaPad0 + kNaPad1) * 4);
+constexpr size_t kNaSecList = kNaSecIdx + align256((size_t)kNaPad0 * 4);
+constexpr size_t kNaSmall = kNaSecList + align256((size_t)2 * kNaPad0 * 4);   // stats 16 B | dims 8 B | pad | rescan count 16 B
 constexpr size_t kNaBytes = kNaSmall + 256;
 
 static __device__ __align__(256) unsigned char scratch[kNaBytes];
@@ -1187,6 +1273,7 @@ int vs_match_two_way_noalloc(const float *desc0, int32_t n0, const float *desc1,
     v.dist0 = (float *)(base + kNaDist0); v.dist1 = (float *)(base + kNaDist1);
     v.second0 = (float *)(base + kNaSecond0);
     v.rescan_list = (int *)(base + kNaRescan);
+    v.sec_idx = (int *)(base + kNaSecIdx); v.sec_list = (int *)(base + kNaSecList);
     v.stats = (unsigned *)(base + kNaSmall); v.dims = (PairDims *)(base + kNaSmall + 16);
     v.rescan_count = (int *)(base + kNaSmall + 64);
     v.xy0 = v.xy1 = nullptr;

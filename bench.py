@@ -349,28 +349,89 @@ def bench_tracking(torch):
     return out
 
 
+def _median_time(fn, passes, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def _normal_equations_pass(orc, sc):
+    """One LM linear step of the c2 shape the way the reference's solver takes it: the full damped
+    normal equations over cameras and points, factored sparse (SuperLU in symmetric mode with a
+    minimum-degree ordering stands in for CHOLMOD, which is not installed) and solved."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    p = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    t0 = time.perf_counter()
+    _, res, Jc, Jp = p.evaluate()
+    No, Nc, Np = sc.No, sc.Nc, sc.Np
+    rows = np.repeat(np.arange(2 * No), 9)
+    cols = np.concatenate([6 * sc.cam[:, None] + np.arange(6), 6 * Nc + 3 * sc.pt[:, None] + np.arange(3)], axis=1)
+    cols = np.repeat(cols, 2, axis=0).reshape(-1)
+    vals = np.concatenate([Jc.reshape(No, 2, 6), Jp.reshape(No, 2, 3)], axis=2).reshape(-1)
+    J = sp.csr_matrix((vals, (rows, cols)), shape=(2 * No, 6 * Nc + 3 * Np))
+    H = (J.T @ J + 1e-4 * sp.identity(J.shape[1])).tocsc()
+    g = J.T @ res.reshape(-1)
+    lu = spl.splu(H, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    lu.solve(-g)
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(name):
-    """The CPU oracle (fp64, one thread) on the same BA workload: residual + Jacobian + Schur."""
+    """The CPU oracle (fp64) on the same BA workload, residual + Jacobian + Schur: one thread (the
+    reference runs its solver on one thread, src/core/tracking.cc:101-103) as the headline, the
+    OpenMP variant on the host cores this process may use beside it; the sparse normal-equation
+    route at the 50-camera shape; one full-size matcher pair on one thread and on all of them."""
+    import ctypes as C
     from oracle import oracle as orc
     from visual_slam_amd import synth
+    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
     sc = synth.make_ba_config(name)
     p = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
-    dc = np.full(6 * sc.Nc, 1e-4); dp = np.full(3 * sc.Np, 1e-4)
-    p.schur(dc=dc, dp=dp)
-    reps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < 10.0:               # a bounded sample: about 10 s of CPU work
-        p.schur(dc=dc, dp=dp)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    out = dict(value=sc.No / dt, unit="observations/s", cores=1, kind="port",
-               sample="%d passes of vo_schur (residual+Jacobian+dense-S Schur, fp64, gcc -O3) over the "
-                      "whole %s problem (%d observations)" % (reps, name, sc.No))
-    d0, d1 = synth.make_descriptors(2048, 2048, seed=0)
-    t0 = time.perf_counter()
-    orc.two_way_matching(d0, d1, 0.7)
-    dm = time.perf_counter() - t0
-    out["matcher"] = dict(value=2048 / dm * (2048.0 / 4096.0), unit="query rows/s at 4096 candidates",
-                          cores=1, kind="port", sample="one 2048x2048 pair, scaled to 4096 candidates per row")
+    n = 6 * sc.Nc
+    dc = np.full(n, 1e-4); dp = np.full(3 * sc.Np, 1e-4)
+    S = np.zeros((n, n)); rhs = np.zeros(n); Vinv = np.zeros((sc.Np, 9)); gp = np.zeros((sc.Np, 3))
+    lib, d = orc.lib(), orc._d
+
+    def one():
+        lib.vo_schur(*p._args(), 0, d(dc), d(dp), d(S), d(rhs), None, None, d(Vinv), d(gp), None)
+
+    def many():
+        lib.vo_schur_mt(threads, *p._args(), d(dc), d(dp), d(S), d(rhs), d(Vinv), d(gp))
+
+    passes = 10
+    dt1 = _median_time(one, passes)
+    dtn = _median_time(many, passes)
+    what = "vo_schur (residual+Jacobian+dense-S Schur, fp64, gcc -O3) over the whole %s problem (%d observations)" % (name, sc.No)
+    out = dict(value=sc.No / dt1, unit="observations/s", cores=1, kind="port",
+               sample="median of %d passes of %s" % (passes, what))
+    out["all_cores"] = dict(value=sc.No / dtn, unit="observations/s", cores=threads, kind="port",
+                            sample="median of %d passes of the OpenMP variant of %s" % (passes, what))
+    # the reference's own route (SPARSE_NORMAL_CHOLESKY, src/core/tracking.cc:103) beside the Schur
+    # route, one linear step each at the 50-camera shape
+    c2 = synth.make_ba_config("c2")
+    dt_ne = _normal_equations_pass(orc, c2)
+    p2 = orc.Problem(c2.K, c2.t0, c2.rpy0, c2.pts0, c2.cam, c2.pt, c2.uv)
+    dt_sc = _median_time(lambda: p2.lm_step(1e4), passes)
+    out["normal_equations"] = dict(value=c2.No / dt_ne, unit="observations/s", cores=1, kind="port", seconds=dt_ne,
+                                   sample="one pass at c2 (%d observations): oracle residual+Jacobian, sparse J^T J "
+                                          "over cameras and points, SuperLU symmetric-mode factorisation + solve "
+                                          "(CHOLMOD is not installed)" % c2.No,
+                                   schur_route=dict(value=c2.No / dt_sc, seconds=dt_sc,
+                                                    sample="median of %d vo_lm_step passes at c2 (Schur + dense "
+                                                           "Cholesky + back-substitution)" % passes))
+    d0, d1 = synth.make_descriptors(4096, 4096, seed=0)
+    dm1 = _median_time(lambda: orc.two_way_matching(d0, d1, 0.7), 3, warm=0)
+    dmn = _median_time(lambda: orc.two_way_matching_mt(threads, d0, d1, 0.7), 5)
+    out["matcher"] = dict(value=4096 / dm1, unit="query rows/s at 4096 candidates", cores=1, kind="port",
+                          sample="median of 3 passes over one 4096x4096 pair (scalar loop, double accumulation)",
+                          all_cores=dict(value=4096 / dmn, cores=threads,
+                                         sample="median of 5 passes, rows spread over OpenMP threads"))
     return out
 
 

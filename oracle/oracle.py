@@ -135,6 +135,17 @@ class Problem:
                        _d(gc), _d(Vinv), _d(gp), _d(V))
         return dict(S=S, rhs=rhs, U=U, gc=gc, Vinv=Vinv, gp=gp, V=V)
 
+    def schur_mt(self, threads, dc=None, dp=None, want_S=True):
+        """vo_schur with free points on `threads` OpenMP threads (bench baseline; same sums in the
+        same order as schur(), so the results are bit-identical)."""
+        n = 6 * self.Nc
+        S = np.zeros((n, n)) if want_S else None
+        rhs = np.zeros(n); Vinv = np.zeros((self.Np, 3, 3)); gp = np.zeros((self.Np, 3))
+        dc = None if dc is None else _f64(dc)
+        dp = None if dp is None else _f64(dp)
+        lib().vo_schur_mt(int(threads), *self._args(), _d(dc), _d(dp), _d(S), _d(rhs), _d(Vinv), _d(gp))
+        return dict(S=S, rhs=rhs, Vinv=Vinv, gp=gp)
+
     def normal_dense(self):
         n = 6 * self.Nc + (0 if self.fix_points else 3 * self.Np)
         H = np.zeros((n, n)); g = np.zeros(n)
@@ -196,6 +207,17 @@ def two_way_matching(d0, d1, nn_thresh=2.0, ratio=1.0):
     d0, d1 = _f32(d0).reshape(-1, 256), _f32(d1).reshape(-1, 256)
     return _matches(lib().vo_two_way_matching, len(d0), _f(d0), len(d0), _f(d1), len(d1),
                     C.c_float(nn_thresh), C.c_float(ratio))
+
+
+def two_way_matching_mt(threads, d0, d1, nn_thresh=2.0, ratio=1.0):
+    d0, d1 = _f32(d0).reshape(-1, 256), _f32(d1).reshape(-1, 256)
+    return _matches(lib().vo_two_way_matching_mt, len(d0), int(threads), _f(d0), len(d0), _f(d1), len(d1),
+                    C.c_float(nn_thresh), C.c_float(ratio))
+
+
+def max_threads():
+    """Threads OpenMP would use by default (OMP_NUM_THREADS, else the cores this process may run on)."""
+    return int(lib().vo_max_threads())
 
 
 def stereo_matching(d0, xy0, d1, xy1, nn_thresh=2.0, ratio=1.0):

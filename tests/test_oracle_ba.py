@@ -150,3 +150,22 @@ def test_pose_codec(orc):
                        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
         assert np.abs(R2 - synth.rpy_to_R(rpy)).max() < 1e-12
+
+
+def test_openmp_variants_return_what_the_one_thread_functions_return(orc):
+    """bench.py times vo_schur_mt / vo_two_way_matching_mt as the all-cores CPU baseline: they take
+    every sum in the one-thread order, so the outputs are bit-identical at any thread count."""
+    for name, huber in (("c1", 100.0), ("c2", 0.0)):
+        sc = synth.make_ba_config(name, seed=3)
+        p = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, huber_a=huber)
+        dc = np.full(6 * sc.Nc, 1e-4); dp = np.full(3 * sc.Np, 2e-4)
+        a = p.schur(dc=dc, dp=dp)
+        for threads in (1, 3):
+            b = p.schur_mt(threads, dc=dc, dp=dp)
+            assert all(np.array_equal(a[k], b[k]) for k in ("S", "rhs", "Vinv", "gp"))
+    d0, d1 = synth.make_descriptors(300, 257, seed=1)
+    d1[5] = d1[9]                                                       # a tie for the first-minimum rule
+    a = orc.two_way_matching(d0, d1, 0.9, 0.8)
+    b = orc.two_way_matching_mt(3, d0, d1, 0.9, 0.8)
+    assert len(a[0]) > 0 and all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert orc.max_threads() >= 1

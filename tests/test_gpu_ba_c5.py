@@ -77,7 +77,7 @@ def test_c5_windows_match_oracle_and_shards_add_up(orc, c5):
         ev = np.abs(Vinv6[pts] - ref6).max(axis=1) / np.abs(ref6).max(axis=1)
         assert ev.max() < 1e-7 and np.median(ev) < 1e-12 and rel(gp[pts], s["gp"]) < 1e-11   # cameras up to 500 m from the origin: R Pw + t cancels three digits
         checked += int(sel.sum())
-    assert checked > 3000
+    assert checked > 2000
     # eight landmark shards (the 8-GPU layout): partial systems add up to the whole
     gpu.linearize(None, dp)
     _, _, S, rhs, cost = gpu.reduced_system()

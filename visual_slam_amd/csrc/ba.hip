@@ -86,6 +86,7 @@ struct vs_ba {
     int max_pair_gap = 0;   // largest |a - b| over the camera pairs of the reduced system
     int nb_off = 0, n_diag_items = 0, n_off_items = 0, n_lm_blocks = 0, n_lm4_blocks = 0, item_waves = 4;
     bool stage_cams = false;
+    int lds_cam_grid = 0;                 // > 0: landmark_lds_kernel (every camera in LDS, one workgroup per CU) with this grid
     int64_t red_len = 0;
     vs_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
@@ -142,6 +143,27 @@ int prep_cameras(vs_ba *h, const real *t, const real *rpy)
 }
 
 // camera records, plus the sines and cosines the landmark kernel keeps behind them
+// Dynamic LDS beyond the default limit for landmark_lds_kernel: a per-device function attribute.
+// The camera array shares the CU's 160 KB with the kernel's 24.1 KB of static LDS.
+constexpr size_t kLdsCamBytesMax = 134 * 1024;
+int landmark_lds_raise_limit()
+{
+    static std::mutex m;
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return VS_ERR_HIP; }
+    std::lock_guard<std::mutex> lock(m);
+    if (!raised[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(landmark_lds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCamBytesMax) != hipSuccess) {
+            set_error("cannot raise the dynamic LDS limit of the landmark kernel");
+            return VS_ERR_HIP;
+        }
+        raised[dev] = true;
+    }
+    return VS_OK;
+}
+
 size_t cam_lds_bytes(const vs_ba *h) { return h->stage_cams ? (size_t)h->Nc * (sizeof(CamData) + 6 * sizeof(real)) : 0; }
 
 // Builds every index structure from the caller's edge list (host side, once per edge set).
@@ -381,6 +403,17 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         }
     }
 
+    // Neither: every camera still fits the LDS of a CU as one array (one persistent workgroup per CU)
+    h->lds_cam_grid = 0;
+    if (!h->stage_cams && h->lm_cam_span == 0 && (size_t)Nc * kCamLdsReals * sizeof(real) <= kLdsCamBytesMax &&
+        getenv("VS_BA_NO_LDS_CAMS") == nullptr) {
+        int dev = 0, cus = 0;
+        VS_HIP(hipGetDevice(&dev));
+        VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        VS_TRY(landmark_lds_raise_limit());
+        h->lds_cam_grid = std::max(1, std::min(cus, div_up(h->n_lm4_blocks, kLmBigThreads / kLmThreads)));
+    }
+
     hipStream_t s = h->stream;
     VS_TRY(h->pt_ptr.upload(pt_ptr.data(), pt_ptr.size(), s));
     VS_TRY(h->lcam.upload(lcam.data(), lcam.size(), s));
@@ -422,8 +455,10 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
 
 // Linearise at parameters (t,rpy,pts on device) and form the undamped-camera reduced system in
 // h->red.  Point damping is applied inside (it is local to a landmark); camera damping later.
-int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDamping pd, const real *lam_c = nullptr)
+int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDamping pd, const real *lam_c = nullptr,
+              bool want_vdiag = false)
 {
+    real *vdiag = want_vdiag ? h->Vdiag.p : nullptr;   // diag(V): only the Jacobi scaling pass reads it
     auto mark = [&](int i) { if (h->prof_ev) (void)hipEventRecord(h->prof_ev[i], h->stream); };
     mark(0);
     // few cameras: the landmark kernel builds the camera records itself (no separate pass)
@@ -433,18 +468,23 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     if (h->stage_cams)
         hipLaunchKernelGGL(landmark_kernel<1>, dim3(h->n_lm4_blocks), dim3(kLmThreads), lds, h->stream,
                            h->Np, h->Nc, h->K, (const CamData *)nullptr, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p,
-                           h->hub, (const int *)nullptr, 0, pd, h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+                           h->hub, (const int *)nullptr, 0, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else if (h->lm_cam_span > 0)
         hipLaunchKernelGGL(landmark_kernel<2>, dim3(h->n_lm4_blocks), dim3(kLmThreads),
                            (size_t)h->lm_cam_span * sizeof(CamData), h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
                            (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->lm_cam_lo.p,
-                           h->lm_cam_span, pd, h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+                           h->lm_cam_span, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
+    else if (h->lds_cam_grid > 0)
+        hipLaunchKernelGGL(landmark_lds_kernel, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
+                           (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
+                           h->Np, h->Nc, h->n_lm4_blocks, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
+                           pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else
         hipLaunchKernelGGL(landmark_kernel<0>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
                            (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, (const int *)nullptr, 0, pd,
-                           h->lmrec.p, h->Vdiag.p, h->hub_w.p, h->cost_partial.p);
+                           h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     VS_TRY(launch_check("landmark_kernel"));
     mark(2);
     {
@@ -552,7 +592,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
         const bool fp = h->fix_points;
         h->fix_points = true;   // only diag(U), diag(V) are needed: skip the Schur terms
-        int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none);
+        int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none, nullptr, true);
         h->fix_points = fp;
         VS_TRY(rc);
         VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));

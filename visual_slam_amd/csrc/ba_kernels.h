@@ -239,73 +239,61 @@ constexpr int kRec = 12;
 constexpr int kLpl = VS_LPL;                          // lanes cooperating on one landmark (power of two)
 constexpr int kLmPerBlock = kLmThreads / kLpl;        // landmarks per workgroup
 
-// (a)+(b), landmark side.  kLpl lanes per landmark j share its observations:
-// V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
-// Cameras come from LDS when they all fit (STAGE 1), or when the cameras seen by the landmarks of
-// one workgroup span a short index range (STAGE 2, cam_lo[workgroup] = first camera of the range,
-// cam_span = longest range: keyframes in time order).  With prep_t / prep_rpy given (STAGE 1 only)
-// every workgroup builds the camera records itself, straight into LDS (which then also holds
-// 6 Nc reals of sines and cosines behind the records), and workgroup 0 also stores them to
-// `cams_out` for the kernels that follow: no separate camera pass.
-template <int STAGE>   // 0: cameras gathered from global memory, 1: all cameras in LDS, 2: this workgroup's camera range in LDS
-__global__ void __launch_bounds__(kLmThreads)
-landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
-                const real *__restrict__ prep_t, const real *__restrict__ prep_rpy,
-                CamData *__restrict__ cams_out,
-                const real *__restrict__ pts, const int *__restrict__ pt_ptr,
-                const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
-                const int *__restrict__ cam_lo, int cam_span, PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
-                real *__restrict__ hub_w, real *__restrict__ cost_partial)
+// Stores the landmark records a wave holds (lane 0 of each group of kLpl lanes has one, for the
+// consecutive landmarks jw, jw + 1, ...) as whole lines: the records of a wave are contiguous in
+// `lmrec`, so they pass through a per-wave LDS staging area (kRecStage reals, half the wave's
+// records at a time) and leave as 16-byte chunks in lane order instead of six scattered 16-byte
+// stores per record.  Only LDS operations of one wave touch the area, and those execute in order.
+constexpr int kRecsPerWave = kWave / kLpl;
+constexpr int kRecStage = (kRecsPerWave / 2) * kRec;
+__device__ __forceinline__ void store_records(real *stage, int lane, int jw, int Np, const double2 *rec,
+                                              real *__restrict__ lmrec)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    CamData *scams = reinterpret_cast<CamData *>(smem_raw);
-    __shared__ real red[4];
-    // the landmark's own data first: these loads are in flight while the cameras are staged
-    const int j = blockIdx.x * kLmPerBlock + (int)threadIdx.x / kLpl;
-    const int sl = threadIdx.x & (kLpl - 1);
-    real P[3] = { 0, 0, 0 };
-    int b = 0, e = 0;
-    if (j < Np) {
-        b = pt_ptr[j]; e = pt_ptr[j + 1];
-        P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
-    }
-    if (STAGE == 1) {
-        if (prep_t) {
-            // one sincos per thread (3 Nc of them) instead of three per camera in a single wave
-            real *sc = reinterpret_cast<real *>(scams + Nc);
-            for (int i = threadIdx.x; i < 3 * Nc; i += blockDim.x) sincos(prep_rpy[i], &sc[2 * i], &sc[2 * i + 1]);
-            __syncthreads();
-            for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
-                const real *q = sc + 6 * c;
-                const CamData d = cam_from_sincos(prep_t, c, q[0], q[1], q[2], q[3], q[4], q[5]);
-                scams[c] = d;
-                if (blockIdx.x == 0) cams_out[c] = d;
-            }
-        } else {
-            const double2 *src = reinterpret_cast<const double2 *>(cams);
-            double2 *dst = reinterpret_cast<double2 *>(scams);
-            for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
+    static_assert(kRec == 12 && kRecsPerWave % 2 == 0, "six 16-byte chunks per record");
+    constexpr int kHalf = kRecsPerWave / 2, kChunks = kHalf * 6;
+    const int r = lane / kLpl;
+    double2 *st = reinterpret_cast<double2 *>(stage);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        __builtin_amdgcn_wave_barrier();
+        if ((lane & (kLpl - 1)) == 0 && r / kHalf == half) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) st[(r - half * kHalf) * 6 + q] = rec[q];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        double2 *dst = reinterpret_cast<double2 *>(lmrec + (int64_t)kRec * (jw + half * kHalf));
+        const int n_valid = min(kHalf, Np - (jw + half * kHalf)) * 6;      // chunks of landmarks that exist
+#pragma unroll
+        for (int c0 = 0; c0 < kChunks; c0 += kWave) {
+            const int c = c0 + lane;
+            if (c < kChunks && c < n_valid) dst[c] = st[c];
+        }
     }
-    int lo = 0;
-    if (STAGE == 2) {
-        lo = cam_lo[blockIdx.x];
-        const int cnt = min(cam_span, Nc - lo);
-        const double2 *src = reinterpret_cast<const double2 *>(cams + lo);
-        double2 *dst = reinterpret_cast<double2 *>(scams);
-        for (int i = threadIdx.x; i < cnt * 8; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-    }
+}
+
+// The work of the kLpl lanes that share landmark j (sl = lane within the group, [b, e) = the
+// landmark's observations, P its position): V_j, g_p_j and the cost over its observations,
+// Vinv_j = (V_j + damping)^-1; lane 0 of the group gets the landmark record in rec[0..6) (the
+// caller stores it, see store_records) and stores diag(V_j) when asked to.
+// (c_first, uv_first) = camera index and pixel of observation b + sl (unused when b + sl >= e),
+// `fetch(c, cd)` delivers camera c's record.  Returns the landmark's cost in lane 0 of the group,
+// zero elsewhere.
+template <typename CamFetch>
+__device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int e, const real *P, const Intr &K,
+                                               const int *__restrict__ lcam, const real *__restrict__ luv,
+                                               const HuberObs &hub, const PointDamping &damp,
+                                               double2 *rec, real *__restrict__ Vdiag,
+                                               real *__restrict__ hub_w, int c_first, double2 uv_first, CamFetch fetch)
+{
     real acc[10];                                      // V (6), g (3), cost
 #pragma unroll
     for (int v = 0; v < 10; v++) acc[v] = real(0);
     if (j < Np) {
         // the next observation's camera index and pixel are fetched while this one is processed
-        int pos = b + sl, c_next = 0;
-        double2 uv_next = make_double2(0, 0);
-        if (pos < e) { c_next = lcam[pos]; uv_next = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)pos); }
-        for (; pos < e; pos += kLpl) {
+        // (the lane's first observation arrives from the caller, who may have fetched it early)
+        int c_next = c_first;
+        double2 uv_next = uv_first;
+        for (int pos = b + sl; pos < e; pos += kLpl) {
             const int c = c_next;
             const double2 uv = uv_next;
             if (pos + kLpl < e) {
@@ -313,7 +301,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                 uv_next = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(pos + kLpl));
             }
             CamData cd;
-            if (STAGE == 0) load_cam(cams, c, cd); else cd = scams[c - lo];
+            fetch(c, cd);
             ObsLin o;
             project_obs(cd, P, uv.x, uv.y, K, o);
             real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
@@ -371,7 +359,6 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
             vi[3] = (a * f - cc * cc) * id; vi[4] = (bb * cc - a * ee) * id;
             vi[5] = (a * d - bb * bb) * id;
         }
-        double2 *rec = reinterpret_cast<double2 *>(lmrec + (int64_t)kRec * j);
         rec[0] = make_double2(P[0], P[1]);
         rec[1] = make_double2(P[2], vi[0]);
         rec[2] = make_double2(vi[1], vi[2]);
@@ -379,8 +366,162 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
         rec[4] = make_double2(vi[5], acc[6]);
         rec[5] = make_double2(acc[7], acc[8]);
     }
+    return cost;
+}
+
+// (a)+(b), landmark side.  kLpl lanes per landmark j share its observations:
+// V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
+// Cameras come from LDS when they all fit (STAGE 1), or when the cameras seen by the landmarks of
+// one workgroup span a short index range (STAGE 2, cam_lo[workgroup] = first camera of the range,
+// cam_span = longest range: keyframes in time order).  With prep_t / prep_rpy given (STAGE 1 only)
+// every workgroup builds the camera records itself, straight into LDS (which then also holds
+// 6 Nc reals of sines and cosines behind the records), and workgroup 0 also stores them to
+// `cams_out` for the kernels that follow: no separate camera pass.
+template <int STAGE>   // 0: cameras gathered from global memory, 1: all cameras in LDS, 2: this workgroup's camera range in LDS
+__global__ void __launch_bounds__(kLmThreads)
+landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
+                const real *__restrict__ prep_t, const real *__restrict__ prep_rpy,
+                CamData *__restrict__ cams_out,
+                const real *__restrict__ pts, const int *__restrict__ pt_ptr,
+                const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
+                const int *__restrict__ cam_lo, int cam_span, PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
+                real *__restrict__ hub_w, real *__restrict__ cost_partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    CamData *scams = reinterpret_cast<CamData *>(smem_raw);
+    __shared__ real red[4];
+    __shared__ __attribute__((aligned(16))) real rec_stage[(kLmThreads / kWave) * kRecStage];
+    // the landmark's own data first: these loads are in flight while the cameras are staged
+    const int j = blockIdx.x * kLmPerBlock + (int)threadIdx.x / kLpl;
+    const int sl = threadIdx.x & (kLpl - 1);
+    real P[3] = { 0, 0, 0 };
+    int b = 0, e = 0;
+    if (j < Np) {
+        b = pt_ptr[j]; e = pt_ptr[j + 1];
+        P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
+    }
+    if (STAGE == 1) {
+        if (prep_t) {
+            // one sincos per thread (3 Nc of them) instead of three per camera in a single wave
+            real *sc = reinterpret_cast<real *>(scams + Nc);
+            for (int i = threadIdx.x; i < 3 * Nc; i += blockDim.x) sincos(prep_rpy[i], &sc[2 * i], &sc[2 * i + 1]);
+            __syncthreads();
+            for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
+                const real *q = sc + 6 * c;
+                const CamData d = cam_from_sincos(prep_t, c, q[0], q[1], q[2], q[3], q[4], q[5]);
+                scams[c] = d;
+                if (blockIdx.x == 0) cams_out[c] = d;
+            }
+        } else {
+            const double2 *src = reinterpret_cast<const double2 *>(cams);
+            double2 *dst = reinterpret_cast<double2 *>(scams);
+            for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+    int lo = 0;
+    if (STAGE == 2) {
+        lo = cam_lo[blockIdx.x];
+        const int cnt = min(cam_span, Nc - lo);
+        const double2 *src = reinterpret_cast<const double2 *>(cams + lo);
+        double2 *dst = reinterpret_cast<double2 *>(scams);
+        for (int i = threadIdx.x; i < cnt * 8; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    int c_first = 0;
+    double2 uv_first = make_double2(0, 0);
+    if (b + sl < e) { c_first = lcam[b + sl]; uv_first = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(b + sl)); }
+    double2 rec[6] = {};
+    const real cost = landmark_lanes(j, sl, Np, b, e, P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_first, uv_first,
+                                     [&](int c, CamData &cd) { if (STAGE == 0) load_cam(cams, c, cd); else cd = scams[c - lo]; });
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        store_records(rec_stage + wave * kRecStage, lane, blockIdx.x * kLmPerBlock + wave * kRecsPerWave, Np, rec, lmrec);
+    }
     const real s = block_sum_256(cost, red);
     if (threadIdx.x == 0) cost_partial[blockIdx.x] = s;
+}
+
+// The landmark kernel for camera counts whose records fit LDS only as a whole-CU array (up to
+// about 1300 cameras): one persistent workgroup of 1024 threads per CU stages every camera once
+// (14 reals each; the 112-byte stride keeps 16-byte reads of consecutive cameras on distinct
+// banks) and then walks tiles of landmarks.  Without it every observation gathers its camera's
+// 112 bytes through the vector cache, whose access rate then bounds the kernel.  Each group of
+// 256 threads handles the landmarks landmark_kernel's workgroup of the same index would, and
+// writes that workgroup's cost partial, so the partials and their sum are the same.
+constexpr int kCamLdsReals = 14;
+constexpr int kLmBigThreads = 1024;
+__global__ void __launch_bounds__(kLmBigThreads)
+landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const CamData *__restrict__ cams,
+                    const real *__restrict__ pts, const int *__restrict__ pt_ptr,
+                    const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
+                    PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
+                    real *__restrict__ hub_w, real *__restrict__ cost_partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2 *scam = reinterpret_cast<double2 *>(smem_raw);
+    __shared__ real red[kLmBigThreads / kWave];
+    __shared__ __attribute__((aligned(16))) real rec_stage[(kLmBigThreads / kWave) * kRecStage];
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(cams);
+        for (int i = threadIdx.x; i < Nc * 7; i += kLmBigThreads) {
+            const int c = i / 7, q = i - 7 * c;
+            scam[i] = src[8 * c + q];
+        }
+    }
+    __syncthreads();
+    const int group = threadIdx.x / kLmThreads, tg = threadIdx.x % kLmThreads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = tg & (kLpl - 1);
+    constexpr int kGroups = kLmBigThreads / kLmThreads;
+    // Two memory latencies precede a landmark's arithmetic (its observation range and position,
+    // then its first observation).  Both are taken off the critical path: the range and position
+    // are fetched two tiles ahead, the first observation one tile ahead.
+    struct Own { int j, b, e; real P[3]; };
+    auto load_own = [&](int t0, Own &o) {
+        const int tile = t0 + group;
+        o.j = tile < n_tiles ? tile * kLmPerBlock + tg / kLpl : Np;
+        o.b = 0; o.e = 0; o.P[0] = o.P[1] = o.P[2] = real(0);
+        if (o.j < Np) {
+            o.b = pt_ptr[o.j]; o.e = pt_ptr[o.j + 1];
+            o.P[0] = pts[3 * o.j]; o.P[1] = pts[3 * o.j + 1]; o.P[2] = pts[3 * o.j + 2];
+        }
+    };
+    auto load_first = [&](const Own &o, int &c, double2 &uv) {
+        c = 0; uv = make_double2(0, 0);
+        if (o.b + sl < o.e) { c = lcam[o.b + sl]; uv = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(o.b + sl)); }
+    };
+    const int stride = gridDim.x * kGroups;
+    Own cur, nxt;
+    int c_cur, c_nxt;
+    double2 uv_cur, uv_nxt;
+    load_own(blockIdx.x * kGroups, cur);
+    load_own(blockIdx.x * kGroups + stride, nxt);
+    load_first(cur, c_cur, uv_cur);
+    for (int t0 = blockIdx.x * kGroups; t0 < n_tiles; t0 += stride) {
+        Own nn;
+        load_own(t0 + 2 * stride, nn);
+        load_first(nxt, c_nxt, uv_nxt);
+        double2 rec[6] = {};
+        real v = landmark_lanes(cur.j, sl, Np, cur.b, cur.e, cur.P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_cur, uv_cur,
+                                [&](int c, CamData &cd) {
+                                    const double2 *src = scam + 7 * c;
+                                    double2 *dst = reinterpret_cast<double2 *>(&cd);
+#pragma unroll
+                                    for (int q = 0; q < 7; q++) dst[q] = src[q];
+                                });
+        if (t0 + group < n_tiles)
+            store_records(rec_stage + wave * kRecStage, lane, (t0 + group) * kLmPerBlock + (tg / kWave) * kRecsPerWave, Np, rec, lmrec);
+        // per-group sum in the order block_sum_256 takes it
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tg == 0 && t0 + group < n_tiles)
+            cost_partial[t0 + group] = red[4 * group] + red[4 * group + 1] + red[4 * group + 2] + red[4 * group + 3];
+        cur = nxt; nxt = nn; c_cur = c_nxt; uv_cur = uv_nxt;
+    }
 }
 
 // Cost only (candidate evaluation inside LM): one thread per landmark.

@@ -143,7 +143,8 @@ int prep_cameras(vs_ba *h, const real *t, const real *rpy)
 }
 
 // camera records, plus the sines and cosines the landmark kernel keeps behind them
-// Dynamic LDS beyond the default limit for landmark_lds_kernel: a per-device function attribute.
+// Dynamic LDS beyond the default limit for landmark_lds_kernel / backsub_lds_kernel: a per-device
+// function attribute.
 // The camera array shares the CU's 160 KB with the kernel's 24.1 KB of static LDS.
 constexpr size_t kLdsCamBytesMax = 134 * 1024;
 int landmark_lds_raise_limit()
@@ -155,6 +156,8 @@ int landmark_lds_raise_limit()
     std::lock_guard<std::mutex> lock(m);
     if (!raised[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(landmark_lds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCamBytesMax) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(backsub_lds_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCamBytesMax) != hipSuccess) {
             set_error("cannot raise the dynamic LDS limit of the landmark kernel");
             return VS_ERR_HIP;
@@ -652,6 +655,11 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
         hipLaunchKernelGGL(backsub_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
+                           h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p,
+                           (int)h->fix_points, h->lmrec.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
+    else if (h->lds_cam_grid > 0)
+        hipLaunchKernelGGL(backsub_lds_kernel, dim3(std::min(h->lds_cam_grid, div_up(h->n_lm_blocks, kLmBigThreads / kLmThreads))),
+                           dim3(kLmBigThreads), (size_t)Nc * kCamLdsReals * sizeof(real), s, Np, Nc, h->n_lm_blocks, h->K,
                            h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p,
                            (int)h->fix_points, h->lmrec.p, h->dcam.p, h->dpt.p, h->mcc_partial.p);
     else

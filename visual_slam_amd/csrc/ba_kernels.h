@@ -1135,9 +1135,79 @@ __global__ void jacobi_scale_kernel(int n, const real *__restrict__ hdiag, real 
     if (i < n) scale[i] = real(1) / (real(1) + sqrt(hdiag[i]));
 }
 
-// Back-substitution and model cost change, one thread per landmark:
-//   dp_j = -Vinv_j (g_p_j + sum_c W_cj^T dc_c), then  mcc -= m (r + m/2), m = Jc dc + Jp dp
-// per residual row.  With fix_points dp = 0.
+// Back-substitution for landmark j (observations [b, e), position P):
+//   dp_j = -(V_j + D)^-1 (g_p_j + sum_o Jp_o^T u_o),   u_o = Jc_o dc_cam(o),
+// written to dpt, and the landmark's share of the model cost change
+//   -sum_o m_o . (r_o + m_o / 2),   m_o = u_o + Jp_o dp_j,
+// which is returned.  One pass over the observations: with q = sum_o Jp_o^T u_o and V = sum_o
+// Jp_o^T Jp_o,  sum_o m.r = sum u.r + dp.g_p  and  sum_o m.m = sum u.u + 2 dp.q + dp^T V dp, so the
+// Jacobians are built once and the camera record and camera step are fetched once per observation.
+// `fetch(c, cd)` delivers camera c's record.
+template <typename CamFetch>
+__device__ __forceinline__ real backsub_landmark(int j, int b, int e, const real *P, const Intr &K,
+                                                 const int *__restrict__ lcam, const real *__restrict__ luv,
+                                                 const HuberObs &hub, const real *__restrict__ hub_w, int fix_points,
+                                                 const real *__restrict__ lmrec, const real *__restrict__ dcam,
+                                                 real *__restrict__ dpt, CamFetch fetch)
+{
+    real dp[3] = { 0, 0, 0 };
+    real mcc = real(0);
+    if (e > b) {
+        real q[3] = { 0, 0, 0 }, V[6] = { 0, 0, 0, 0, 0, 0 }, s_ur = real(0), s_uu = real(0);
+        int c_next = lcam[b];
+        double2 uv_next = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)b);
+        for (int pos = b; pos < e; pos++) {
+            const int c = c_next;
+            const double2 uv = uv_next;
+            if (pos + 1 < e) {
+                c_next = lcam[pos + 1];
+                uv_next = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(pos + 1));
+            }
+            const double2 *dsrc = reinterpret_cast<const double2 *>(dcam + 6 * (int64_t)c);
+            const double2 d01 = dsrc[0], d23 = dsrc[1], d45 = dsrc[2];
+            CamData cd;
+            fetch(c, cd);
+            ObsLin o;
+            project_obs(cd, P, uv.x, uv.y, K, o);
+            if (pos == hub.pos) scale_lin(o, *hub_w);
+            real Jc[12], Jp[6];
+            camera_jac(cd, o, P, Jc);
+            point_jac(cd, o, Jp);
+            const real d[6] = { d01.x, d01.y, d23.x, d23.y, d45.x, d45.y };
+            real u0 = 0, u1 = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { u0 += Jc[k] * d[k]; u1 += Jc[6 + k] * d[k]; }
+            s_ur += u0 * o.r0 + u1 * o.r1;
+            s_uu += u0 * u0 + u1 * u1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) q[k] += Jp[k] * u0 + Jp[3 + k] * u1;
+            V[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3]; V[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
+            V[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5]; V[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4];
+            V[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5]; V[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
+        }
+        // (the record is fetched here, not before the loop, so that it holds no registers across it)
+        real rec[kRec];
+        load_rec(lmrec, j, rec, 6);
+        const real *vi = rec + 3, *gp = rec + 9;
+        if (!fix_points) {
+            const real a0 = gp[0] + q[0], a1 = gp[1] + q[1], a2 = gp[2] + q[2];
+            dp[0] = -(vi[0] * a0 + vi[1] * a1 + vi[2] * a2);
+            dp[1] = -(vi[1] * a0 + vi[3] * a1 + vi[4] * a2);
+            dp[2] = -(vi[2] * a0 + vi[4] * a1 + vi[5] * a2);
+        }
+        const real Vd0 = V[0] * dp[0] + V[1] * dp[1] + V[2] * dp[2];
+        const real Vd1 = V[1] * dp[0] + V[3] * dp[1] + V[4] * dp[2];
+        const real Vd2 = V[2] * dp[0] + V[4] * dp[1] + V[5] * dp[2];
+        const real dp_g = dp[0] * gp[0] + dp[1] * gp[1] + dp[2] * gp[2];
+        const real dp_q = dp[0] * q[0] + dp[1] * q[1] + dp[2] * q[2];
+        const real dp_V_dp = dp[0] * Vd0 + dp[1] * Vd1 + dp[2] * Vd2;
+        mcc = -((s_ur + dp_g) + real(0.5) * (s_uu + real(2) * dp_q + dp_V_dp));
+    }
+    dpt[3 * j] = dp[0]; dpt[3 * j + 1] = dp[1]; dpt[3 * j + 2] = dp[2];
+    return mcc;
+}
+
+// Back-substitution, one thread per landmark; mcc_partial gets one sum per 256 landmarks.
 template <bool STAGE_CAMS>
 __global__ void __launch_bounds__(kLmThreads)
 backsub_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
@@ -1161,58 +1231,61 @@ backsub_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
     if (j < Np) {
         const int b = pt_ptr[j], e = pt_ptr[j + 1];
         const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
-        real dp[3] = { 0, 0, 0 };
-        if (!fix_points && e > b) {
-            const real *gpj = lmrec + (int64_t)kRec * j + 9;
-            real acc[3] = { gpj[0], gpj[1], gpj[2] };
-            for (int pos = b; pos < e; pos++) {
-                const int c = lcam[pos];
-                CamData cd;
-                if (STAGE_CAMS) cd = scams[c]; else load_cam(cams, c, cd);
-                ObsLin o;
-                project_obs(cd, P, real(0), real(0), K, o);
-                if (pos == hub.pos) scale_lin(o, *hub_w);
-                real Jc[12], Jp[6];
-                camera_jac(cd, o, P, Jc);
-                point_jac(cd, o, Jp);
-                real m0 = 0, m1 = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const real d = dcam[6 * c + k];
-                    m0 += Jc[k] * d; m1 += Jc[6 + k] * d;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; k++) acc[k] += Jp[k] * m0 + Jp[3 + k] * m1;
-            }
-            const real *vi = lmrec + (int64_t)kRec * j + 3;
-            dp[0] = -(vi[0] * acc[0] + vi[1] * acc[1] + vi[2] * acc[2]);
-            dp[1] = -(vi[1] * acc[0] + vi[3] * acc[1] + vi[4] * acc[2]);
-            dp[2] = -(vi[2] * acc[0] + vi[4] * acc[1] + vi[5] * acc[2]);
-        }
-        dpt[3 * j] = dp[0]; dpt[3 * j + 1] = dp[1]; dpt[3 * j + 2] = dp[2];
-        for (int pos = b; pos < e; pos++) {
-            const int c = lcam[pos];
-            CamData cd;
-            if (STAGE_CAMS) cd = scams[c]; else load_cam(cams, c, cd);
-            ObsLin o;
-            project_obs(cd, P, luv[2 * pos], luv[2 * pos + 1], K, o);
-            if (pos == hub.pos) scale_lin(o, *hub_w);
-            real Jc[12], Jp[6];
-            camera_jac(cd, o, P, Jc);
-            point_jac(cd, o, Jp);
-            real m0 = 0, m1 = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const real d = dcam[6 * c + k];
-                m0 += Jc[k] * d; m1 += Jc[6 + k] * d;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) { m0 += Jp[k] * dp[k]; m1 += Jp[3 + k] * dp[k]; }
-            mcc -= m0 * (o.r0 + real(0.5) * m0) + m1 * (o.r1 + real(0.5) * m1);
-        }
+        mcc = backsub_landmark(j, b, e, P, K, lcam, luv, hub, hub_w, fix_points, lmrec, dcam, dpt,
+                               [&](int c, CamData &cd) { if (STAGE_CAMS) cd = scams[c]; else load_cam(cams, c, cd); });
     }
     const real s = block_sum_256(mcc, red);
     if (threadIdx.x == 0) mcc_partial[blockIdx.x] = s;
+}
+
+// The same with every camera record in LDS (see landmark_lds_kernel): one persistent workgroup
+// of 1024 threads per CU; each group of 256 threads handles the landmarks backsub_kernel's
+// workgroup of the same index would and writes that workgroup's partial.
+__global__ void __launch_bounds__(kLmBigThreads)
+backsub_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const CamData *__restrict__ cams,
+                   const real *__restrict__ pts, const int *__restrict__ pt_ptr,
+                   const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
+                   const real *__restrict__ hub_w, int fix_points, const real *__restrict__ lmrec,
+                   const real *__restrict__ dcam, real *__restrict__ dpt,
+                   real *__restrict__ mcc_partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2 *scam = reinterpret_cast<double2 *>(smem_raw);
+    __shared__ real red[kLmBigThreads / kWave];
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(cams);
+        for (int i = threadIdx.x; i < Nc * 7; i += kLmBigThreads) {
+            const int c = i / 7, q = i - 7 * c;
+            scam[i] = src[8 * c + q];
+        }
+    }
+    __syncthreads();
+    const int group = threadIdx.x / kLmThreads, tg = threadIdx.x % kLmThreads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kGroups = kLmBigThreads / kLmThreads;
+    for (int t0 = blockIdx.x * kGroups; t0 < n_tiles; t0 += gridDim.x * kGroups) {
+        const int tile = t0 + group;
+        const int j = tile * kLmThreads + tg;
+        real v = real(0);
+        if (tile < n_tiles && j < Np) {
+            const int b = pt_ptr[j], e = pt_ptr[j + 1];
+            const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
+            v = backsub_landmark(j, b, e, P, K, lcam, luv, hub, hub_w, fix_points, lmrec, dcam, dpt,
+                                 [&](int c, CamData &cd) {
+                                     const double2 *src = scam + 7 * c;
+                                     double2 *dst = reinterpret_cast<double2 *>(&cd);
+#pragma unroll
+                                     for (int q = 0; q < 7; q++) dst[q] = src[q];
+                                 });
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tg == 0 && tile < n_tiles)
+            mcc_partial[tile] = red[4 * group] + red[4 * group + 1] + red[4 * group + 2] + red[4 * group + 3];
+    }
 }
 
 // out = max of in[0..n) (single wave).

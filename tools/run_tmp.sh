@@ -1,4 +1,3 @@
 set -e
-timeout -k 10 600 python -u -m pytest tests/test_gpu_ba_fullsize.py tests/test_gpu_ba.py tests/test_gpu_shard_solve.py tests/test_gpu_cpp_adapter.py -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3
-timeout -k 10 300 python3 tools/time_lm.py c2 c4 c5shard c5
-VS_BA_NO_LDS_CAMS=1 timeout -k 10 300 python3 tools/time_lm.py c4
+timeout -k 10 600 python -u -m pytest tests/test_gpu_ba.py tests/test_gpu_ba_fullsize.py tests/test_gpu_shard_solve.py -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3
+timeout -k 10 300 python3 tools/time_lm.py c4 c5shard c5

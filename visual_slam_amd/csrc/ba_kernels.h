@@ -1085,10 +1085,23 @@ step_scalars_kernel(int n_mcc, const real *__restrict__ mcc_partial, int n_pairs
                     real *__restrict__ out)
 {
     __shared__ real red[4];
-    real m = real(0), a = real(0), b = real(0), c = real(0);
-    for (int i = threadIdx.x; i < n_mcc; i += 256) m += mcc_partial[i];
-    for (int i = threadIdx.x; i < n_pairs; i += 256) { a += pair_partial[2 * (int64_t)i]; b += pair_partial[2 * (int64_t)i + 1]; }
-    for (int i = threadIdx.x; i < n_cost; i += 256) c += cost_partial[i];
+    // four loads in flight per thread and sum (a dependent load per addition would cost one memory
+    // latency per partial); the order is fixed
+    auto strided_sum = [&](const real *__restrict__ p, int n, int stride, int offset) {
+        real s0 = real(0), s1 = real(0), s2 = real(0), s3 = real(0);
+        int i = threadIdx.x;
+        for (; i + 768 < n; i += 1024) {
+            const real v0 = p[(int64_t)i * stride + offset], v1 = p[(int64_t)(i + 256) * stride + offset],
+                       v2 = p[(int64_t)(i + 512) * stride + offset], v3 = p[(int64_t)(i + 768) * stride + offset];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; i < n; i += 256) s0 += p[(int64_t)i * stride + offset];
+        return (s0 + s1) + (s2 + s3);
+    };
+    real m = strided_sum(mcc_partial, n_mcc, 1, 0);
+    real a = strided_sum(pair_partial, n_pairs, 2, 0);
+    real b = strided_sum(pair_partial, n_pairs, 2, 1);
+    real c = strided_sum(cost_partial, n_cost, 1, 0);
     m = block_sum_256(m, red);
     a = block_sum_256(a, red);
     b = block_sum_256(b, red);

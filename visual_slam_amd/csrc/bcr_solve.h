@@ -93,8 +93,7 @@ bcr_trsm_kernel(int level, int Nb, int w, const real *__restrict__ D, const real
     }
     __syncthreads();
     // right-looking sweep: solve panel q with its block inverse, then take its contribution out of
-    // every row below (the factor's rows come straight from L2: a row's 32 values are the same for
-    // the 32 threads of a row group)
+    // every row below
     for (int q = 0; q < nt; q++) {
         for (int e = tid; e < kBcrT * kBcrT; e += 256) Lt[e / kBcrT][e % kBcrT] = Li[(int64_t)q * kBcrT * kBcrT + e];
         __syncthreads();
@@ -109,19 +108,36 @@ bcr_trsm_kernel(int level, int Nb, int w, const real *__restrict__ D, const real
 #pragma unroll
         for (int a = 0; a < 4; a++) X[q * kBcrT + ty * 4 + a][tx] = out[a];
         __syncthreads();
-        for (int row0 = (q + 1) * kBcrT + ty * 4; row0 < w; row0 += 32) {
-            real acc[4];
+        // rows below the panel: 32 x 32 tiles of X, one wave each, a 4 x 4 patch per thread (the
+        // factor's rows come from L2 as 16-byte loads, eight distinct rows per wave and load)
+        {
+            const int wv = tid >> 6, r4 = (tid & 63) >> 3, c4 = tid & 7;
+            for (int rb = q + 1 + wv; rb < nt; rb += 4) {
+                const int row0 = rb * kBcrT + r4 * 4, col = c4 * 4;
+                real acc[4][4];
 #pragma unroll
-            for (int a = 0; a < 4; a++) acc[a] = X[row0 + a][tx];
-            const real *Lr = Lc + (int64_t)row0 * w + q * kBcrT;
-#pragma unroll 8
-            for (int k = 0; k < kBcrT; k++) {
-                const real xv = X[q * kBcrT + k][tx];
+                for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int a = 0; a < 4; a++) acc[a] = fma(-Lr[(int64_t)a * w + k], xv, acc[a]);
+                    for (int c2 = 0; c2 < 4; c2++) acc[a][c2] = X[row0 + a][col + c2];
+                const real *Lr = Lc + (int64_t)row0 * w + q * kBcrT;
+#pragma unroll 4
+                for (int k = 0; k < kBcrT; k += 2) {
+                    double2 lv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) lv[a] = *reinterpret_cast<const double2 *>(Lr + (int64_t)a * w + k);
+                    real x0[4], x1[4];
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; c2++) { x0[c2] = X[q * kBcrT + k][col + c2]; x1[c2] = X[q * kBcrT + k + 1][col + c2]; }
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; c2++) acc[a][c2] = fma(-lv[a].y, x1[c2], fma(-lv[a].x, x0[c2], acc[a][c2]));
+                }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; c2++) X[row0 + a][col + c2] = acc[a][c2];
             }
-#pragma unroll
-            for (int a = 0; a < 4; a++) X[row0 + a][tx] = acc[a];
         }
         __syncthreads();
     }
@@ -133,91 +149,118 @@ bcr_trsm_kernel(int level, int Nb, int w, const real *__restrict__ D, const real
     }
 }
 
-// 32 x 32 tile of  P^T Q  (P, Q: w x w row-major, the sum runs over their rows): thread (tx, ty)
-// adds rows ty*4 .. ty*4+3 of column tx to acc.
+constexpr int kBcrKC = 16;          // rows of P and Q staged per step of a tile product
+
+// 32 x 32 tile of  P^T Q  (P, Q: w x w row-major, the sum runs over their rows) by ONE wave: 16
+// rows of both operands at a time pass through the wave's own LDS area, every lane adds a 4 x 4
+// patch (rows r4*4.., columns c4*4.. of the tile): four 16-byte LDS reads per 16 FMAs.  Only this
+// wave touches Ps / Qs, and a wave's LDS operations execute in order: no workgroup barrier.
 __device__ __forceinline__ void bcr_tile_ptq(const real *__restrict__ P, const real *__restrict__ Q, int w,
-                                             int i0, int j0, real (*Ps)[kBcrT + 1], real (*Qs)[kBcrT + 1],
-                                             int tid, real *acc)
+                                             int i0, int j0, real (*Ps)[kBcrT], real (*Qs)[kBcrT],
+                                             int lane, real (*acc)[4])
 {
-    const int tx = tid & 31, ty = tid >> 5;
-    for (int k0 = 0; k0 < w; k0 += kBcrT) {
-        for (int e = tid; e < kBcrT * kBcrT; e += 256) {
+    const int r4 = lane >> 3, c4 = lane & 7;
+    for (int k0 = 0; k0 < w; k0 += kBcrKC) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = lane; e < kBcrKC * kBcrT; e += kWave) {
             const int k = e / kBcrT, m = e % kBcrT;
             Ps[k][m] = P[(int64_t)(k0 + k) * w + i0 + m];
             Qs[k][m] = Q[(int64_t)(k0 + k) * w + j0 + m];
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < kBcrT; k++) {
-            const real qv = Qs[k][tx];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int k = 0; k < kBcrKC; k++) {
+            const double2 p01 = *reinterpret_cast<const double2 *>(&Ps[k][r4 * 4]);
+            const double2 p23 = *reinterpret_cast<const double2 *>(&Ps[k][r4 * 4 + 2]);
+            const double2 q01 = *reinterpret_cast<const double2 *>(&Qs[k][c4 * 4]);
+            const double2 q23 = *reinterpret_cast<const double2 *>(&Qs[k][c4 * 4 + 2]);
+            const real pv[4] = { p01.x, p01.y, p23.x, p23.y }, qv[4] = { q01.x, q01.y, q23.x, q23.y };
 #pragma unroll
-            for (int a = 0; a < 4; a++) acc[a] = fma(Ps[k][ty * 4 + a], qv, acc[a]);
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) acc[a][c2] = fma(pv[a], qv[c2], acc[a][c2]);
         }
-        __syncthreads();
     }
 }
 
-// Updates of one level.  blockIdx.y < n_rem: staying block t = 2s - 1 + 2s * blockIdx.y loses the
-// Schur terms of the blocks leaving on its left (c = t - s, through G_r) and on its right
-// (c = t + s, through G_l): lower tiles of D_t (blockIdx.x < n_lower) and b_t (blockIdx.x == n_lower).
+// Updates of one level, four 32 x 32 output tiles per workgroup (one per wave).
+// blockIdx.y < n_rem: staying block t = 2s - 1 + 2s * blockIdx.y loses the Schur terms of the
+// blocks leaving on its left (c = t - s, through G_r) and on its right (c = t + s, through G_l):
+// lower tiles of D_t, and b_t (the workgroup with blockIdx.x == gridDim.x - 1).
 // blockIdx.y >= n_rem: leaving block c with both neighbours creates the coupling A_{r,l} =
-// -G_r^T G_l (blockIdx.x < nt * nt).  Every output tile has one writer.
+// -G_r^T G_l (nt * nt tiles).  Every output tile has one writer.
 __global__ void __launch_bounds__(256)
 bcr_update_kernel(int level, int Nb, int w, int n_rem, const real *__restrict__ Gl,
                   const real *__restrict__ Gr, const real *__restrict__ z, real *__restrict__ D,
                   real *__restrict__ C, real *__restrict__ b)
 {
-    __shared__ real Ps[kBcrT][kBcrT + 1];
-    __shared__ real Qs[kBcrT][kBcrT + 1];
+    __shared__ __attribute__((aligned(16))) real Ps[4][kBcrKC][kBcrT];
+    __shared__ __attribute__((aligned(16))) real Qs[4][kBcrKC][kBcrT];
     const int s = 1 << level, nt = w / kBcrT, n_lower = nt * (nt + 1) / 2;
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int lane = tid & 63, wv = tid >> 6;
     const int64_t ww = (int64_t)w * w;
-    const int item = blockIdx.y, tile = blockIdx.x;
-    real acc[4] = { 0, 0, 0, 0 };
+    const int item = blockIdx.y;
+    if (blockIdx.x == gridDim.x - 1) {
+        if (item >= n_rem) return;
+        // right-hand side: b_t -= G_r(cL)^T z(cL) + G_l(cR)^T z(cR)
+        // thread (i mod 32, part): column i of the block, every eighth row
+        const int t = 2 * s - 1 + item * 2 * s;
+        const int cL = t - s, cR = t + s;
+        real *red = &Ps[0][0][0];                   // 8 x 33 partial sums
+        for (int i0 = 0; i0 < w; i0 += kBcrT) {
+            real sum = real(0);
+            const real *G = Gr + cL * ww, *zz = z + (int64_t)cL * w;
+            for (int k = ty; k < w; k += 8) sum = fma(G[(int64_t)k * w + i0 + tx], zz[k], sum);
+            if (cR < Nb) {
+                G = Gl + cR * ww; zz = z + (int64_t)cR * w;
+                for (int k = ty; k < w; k += 8) sum = fma(G[(int64_t)k * w + i0 + tx], zz[k], sum);
+            }
+            red[ty * (kBcrT + 1) + tx] = sum;
+            __syncthreads();
+            if (ty == 0) {
+                real tot = real(0);
+#pragma unroll
+                for (int part = 0; part < 8; part++) tot += red[part * (kBcrT + 1) + tx];
+                b[(int64_t)t * w + i0 + tx] -= tot;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int tile = (int)blockIdx.x * 4 + wv;
+    const int r4 = lane >> 3, c4 = lane & 7;
+    real acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int c2 = 0; c2 < 4; c2++) acc[a][c2] = real(0);
     if (item < n_rem) {
         const int t = 2 * s - 1 + item * 2 * s;
         const int cL = t - s, cR = t + s;
-        if (tile > n_lower) return;
-        if (tile == n_lower) {                      // right-hand side: b_t -= G_r(cL)^T z(cL) + G_l(cR)^T z(cR)
-            // thread (i mod 32, part): column i of the block, every eighth row
-            real *red = &Ps[0][0];                  // 8 x 32 partial sums
-            for (int i0 = 0; i0 < w; i0 += kBcrT) {
-                real sum = real(0);
-                const real *G = Gr + cL * ww, *zz = z + (int64_t)cL * w;
-                for (int k = ty; k < w; k += 8) sum = fma(G[(int64_t)k * w + i0 + tx], zz[k], sum);
-                if (cR < Nb) {
-                    G = Gl + cR * ww; zz = z + (int64_t)cR * w;
-                    for (int k = ty; k < w; k += 8) sum = fma(G[(int64_t)k * w + i0 + tx], zz[k], sum);
-                }
-                red[ty * (kBcrT + 1) + tx] = sum;
-                __syncthreads();
-                if (ty == 0) {
-                    real tot = real(0);
-#pragma unroll
-                    for (int part = 0; part < 8; part++) tot += red[part * (kBcrT + 1) + tx];
-                    b[(int64_t)t * w + i0 + tx] -= tot;
-                }
-                __syncthreads();
-            }
-            return;
-        }
+        if (tile >= n_lower) return;
         int ti = 0, rem = tile;
         while (rem > ti) { rem -= ti + 1; ti++; }   // tile -> (ti, tj), tj <= ti
         const int tj = rem;
-        bcr_tile_ptq(Gr + cL * ww, Gr + cL * ww, w, ti * kBcrT, tj * kBcrT, Ps, Qs, tid, acc);
-        if (cR < Nb) bcr_tile_ptq(Gl + cR * ww, Gl + cR * ww, w, ti * kBcrT, tj * kBcrT, Ps, Qs, tid, acc);
-        real *out = D + t * ww;
+        bcr_tile_ptq(Gr + cL * ww, Gr + cL * ww, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
+        if (cR < Nb) bcr_tile_ptq(Gl + cR * ww, Gl + cR * ww, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
+        real *out = D + t * ww + (int64_t)(ti * kBcrT + r4 * 4) * w + tj * kBcrT + c4 * 4;
 #pragma unroll
-        for (int a = 0; a < 4; a++) out[(int64_t)(ti * kBcrT + ty * 4 + a) * w + tj * kBcrT + tx] -= acc[a];
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) out[(int64_t)a * w + c2] -= acc[a][c2];
     } else {
         const int c = s - 1 + (item - n_rem) * 2 * s;
         const int l = c - s, r = c + s;
         if (l < 0 || r >= Nb || c >= Nb || tile >= nt * nt) return;
         const int ti = tile / nt, tj = tile % nt;   // rows of r, columns of l
-        bcr_tile_ptq(Gr + c * ww, Gl + c * ww, w, ti * kBcrT, tj * kBcrT, Ps, Qs, tid, acc);
-        real *out = C + l * ww;
+        bcr_tile_ptq(Gr + c * ww, Gl + c * ww, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
+        real *out = C + l * ww + (int64_t)(ti * kBcrT + r4 * 4) * w + tj * kBcrT + c4 * 4;
 #pragma unroll
-        for (int a = 0; a < 4; a++) out[(int64_t)(ti * kBcrT + ty * 4 + a) * w + tj * kBcrT + tx] = -acc[a];
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) out[(int64_t)a * w + c2] = -acc[a][c2];
     }
 }
 
@@ -352,7 +395,7 @@ static inline int bcr_solve(const BcrPlan &p, real *ws, int Nc, int nb_off, cons
                            buf_rows, (int64_t)(2 * st) * (int64_t)ww, (int64_t)(2 * st) * nt * kBcrT * kBcrT);
         hipLaunchKernelGGL(bcr_trsm_kernel, dim3(2 * nt + 1, n_elim), dim3(256), 0, s, level, p.Nb, p.w, D, Linv, C, b, Gl, Gr, z);
         if (n_rem > 0)
-            hipLaunchKernelGGL(bcr_update_kernel, dim3(std::max(nt * nt, nt * (nt + 1) / 2 + 1), n_rem + n_elim), dim3(256), 0, s,
+            hipLaunchKernelGGL(bcr_update_kernel, dim3(div_up(std::max(nt * nt, nt * (nt + 1) / 2), 4) + 1, n_rem + n_elim), dim3(256), 0, s,
                                level, p.Nb, p.w, n_rem, Gl, Gr, z, D, C, b);
     }
     for (int level = p.levels - 1; level >= 0; level--) {

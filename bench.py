@@ -139,12 +139,23 @@ def bench_ba(args, rank, world, dist, torch, comm):
         dom = max(k_ms, key=k_ms.get)
         achieved = alg / (kern_sum * 1e-3) / 1e9
         traffic, traffic_src = committed_traffic(args.workload) if world == 1 else (None, None)
+        # the block kernel is bound by fp64 issue, not by HBM: its VALU wave-instructions (committed
+        # counter pass) at one per 4 cycles and SIMD, against its measured duration
+        valu = committed_valu_instructions(args.workload) if world == 1 else None
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        clock_hz = float(getattr(props, "clock_rate", 0) or 2.4e6) * 1e3
+        valu_frac = None
+        if valu and k_ms.get("blocks(camera+camera-pair)"):
+            ideal_s = valu * 4.0 / (props.multi_processor_count * 4 * clock_hz)
+            valu_frac = ideal_s / (k_ms["blocks(camera+camera-pair)"] * 1e-3)
         out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                                frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                               kernel="fused linearise pipeline: landmark + blocks kernels (plus prep_cameras when the "
-                                      "cameras do not fit LDS and finalize when a block spans several work items; at "
-                                      "50 cameras those two intervals are empty). HIP-event intervals, each carrying "
-                                      "~5 us of event overhead, so the sum is longer than the timed step",
+                               fp64_valu_frac=valu_frac,
+                               fp64_valu_note="block kernel: SQ_INSTS_VALU (committed counter pass) x 4 cycles / "
+                                              "(SIMDs x %.2f GHz) / its measured duration" % (clock_hz / 1e9),
+                               kernel="fused linearise pipeline: camera records, landmark kernel, block kernels, "
+                                      "and finalize when a block spans several work items. HIP-event intervals, "
+                                      "each carrying ~5 us of event overhead, so the sum is longer than the timed step",
                                dominant_kernel=dom, kernels_ms=k_ms, pipeline_ms=float(ms[5]),
                                algorithmic_bytes=int(alg))
     if rank == 0 and world == 1 and not args.no_extra:
@@ -184,10 +195,24 @@ def committed_traffic(workload):
     f, w = pmc.get(workload + "_fetch"), pmc.get(workload + "_write")
     if not f or not w:
         return None, None
-    keys = ("prep_cameras_kernel", "landmark_kernel", "blocks_kernel", "finalize_kernel")
+    keys = ("prep_cameras_kernel", "landmark_", "blocks_", "finalize_kernel")
     fetch = sum(v["FETCH_SIZE"] for k, v in f.items() if any(x in k for x in keys))
     write = sum(v["WRITE_SIZE"] for k, v in w.items() if any(x in k for x in keys))
     return int((2.0 * fetch + write) * 1024), os.path.basename(files[-1])
+
+
+def committed_valu_instructions(workload):
+    """VALU wave-instructions of the block kernels per linearise pass (SQ_INSTS_VALU of the committed
+    rocprofv3 PMC pass), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_summary.json")))
+    if not files:
+        return None
+    v = json.load(open(files[-1])).get("pmc_avg_per_dispatch", {}).get(workload + "_valu")
+    if not v:
+        return None
+    n = sum(c.get("SQ_INSTS_VALU", 0.0) for k, c in v.items() if "blocks_" in k)
+    return n or None
 
 
 def kernel_times(ms):

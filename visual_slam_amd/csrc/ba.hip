@@ -465,7 +465,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     auto mark = [&](int i) { if (h->prof_ev) (void)hipEventRecord(h->prof_ev[i], h->stream); };
     mark(0);
     // few cameras: the landmark kernel builds the camera records itself (no separate pass)
-    if (!h->stage_cams) VS_TRY(prep_cameras(h, t, rpy));
+    if (!h->stage_cams && h->lds_cam_grid == 0) VS_TRY(prep_cameras(h, t, rpy));
     mark(1);
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
@@ -481,7 +481,7 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     else if (h->lds_cam_grid > 0)
         hipLaunchKernelGGL(landmark_lds_kernel, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
                            (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
-                           h->Np, h->Nc, h->n_lm4_blocks, h->K, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
+                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
                            pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else
         hipLaunchKernelGGL(landmark_kernel<0>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,

@@ -445,14 +445,16 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
 // The landmark kernel for camera counts whose records fit LDS only as a whole-CU array (up to
 // about 1300 cameras): one persistent workgroup of 1024 threads per CU stages every camera once
 // (14 reals each; the 112-byte stride keeps 16-byte reads of consecutive cameras on distinct
-// banks) and then walks tiles of landmarks.  Without it every observation gathers its camera's
+// banks; built from the camera parameters by the workgroup itself) and then walks tiles of
+// landmarks.  Without it every observation gathers its camera's
 // 112 bytes through the vector cache, whose access rate then bounds the kernel.  Each group of
 // 256 threads handles the landmarks landmark_kernel's workgroup of the same index would, and
 // writes that workgroup's cost partial, so the partials and their sum are the same.
 constexpr int kCamLdsReals = 14;
 constexpr int kLmBigThreads = 1024;
 __global__ void __launch_bounds__(kLmBigThreads)
-landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const CamData *__restrict__ cams,
+landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict__ prep_t,
+                    const real *__restrict__ prep_rpy, CamData *__restrict__ cams_out,
                     const real *__restrict__ pts, const int *__restrict__ pt_ptr,
                     const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
                     PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
@@ -462,12 +464,14 @@ landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const CamData *__restri
     double2 *scam = reinterpret_cast<double2 *>(smem_raw);
     __shared__ real red[kLmBigThreads / kWave];
     __shared__ __attribute__((aligned(16))) real rec_stage[(kLmBigThreads / kWave) * kRecStage];
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(cams);
-        for (int i = threadIdx.x; i < Nc * 7; i += kLmBigThreads) {
-            const int c = i / 7, q = i - 7 * c;
-            scam[i] = src[8 * c + q];
-        }
+    // every workgroup builds the camera records itself, straight into LDS (one camera per thread
+    // and pass); workgroup 0 also stores them for the kernels that follow: no separate camera pass
+    for (int c = threadIdx.x; c < Nc; c += kLmBigThreads) {
+        const CamData d = make_cam(prep_t, prep_rpy, c);
+        const double2 *src = reinterpret_cast<const double2 *>(&d);
+#pragma unroll
+        for (int q = 0; q < 7; q++) scam[7 * c + q] = src[q];
+        if (blockIdx.x == 0) cams_out[c] = d;
     }
     __syncthreads();
     const int group = threadIdx.x / kLmThreads, tg = threadIdx.x % kLmThreads;

@@ -210,6 +210,23 @@ int vs_matcher_get_nn(vs_matcher_handle m, int32_t pair, int32_t *idx0, int32_t 
  * in the last run (diagnostic). */
 int vs_matcher_get_rescans(vs_matcher_handle m, int64_t *n_rescanned);
 
+/* One frame pair split over several GPUs by QUERY ROWS (no counterpart in the reference, whose
+ * matcher is one loop nest, superpoint_frontend.cc:173-209; this is its row-sharded form): every
+ * rank loads its slice of desc0 (rows row0 .. row0+n0-1 of the whole frame) and ALL of desc1 with
+ * vs_matcher_set_pair, then calls vs_matcher_run_sharded instead of vs_matcher_run.  The row
+ * nearest neighbours are local; the column nearest neighbours (the mutual check,
+ * superpoint_frontend.cc:197-209) are combined across ranks as the minimum of packed
+ * (distance bits, global row) keys -- equal distances resolve to the smaller row, the reference's
+ * first minimum -- by an RCCL all-reduce on the matcher's stream (vs_matcher_set_comm) or by a
+ * callback (vs_matcher_set_min_allreduce: must leave the element-wise minimum over ranks of the n
+ * uint64 at device_buf in place and return 0; the stream is synchronised before the call).
+ * vs_matcher_get_matches then returns this rank's matches with GLOBAL row numbers, ordered by
+ * row; the ranks' lists concatenated in rank order are the whole pair's matches. */
+typedef int (*vs_allreduce_min_u64_fn)(void *user, void *device_buf, int64_t n);
+int vs_matcher_set_comm(vs_matcher_handle m, vs_comm_handle c);
+int vs_matcher_set_min_allreduce(vs_matcher_handle m, vs_allreduce_min_u64_fn fn, void *user);
+int vs_matcher_run_sharded(vs_matcher_handle m, int32_t n_pairs, int32_t row0, float nn_thresh, float ratio);
+
 /* Measurement aid (no counterpart in the reference): vs_matcher_run `iters` times with HIP events
  * between its stages; avg_ms[0..3] = MFMA dot + top-2 kernel, partial merge, exact distance and
  * rescan kernels, mutual-check compaction; avg_ms[4] = first event to last. */

@@ -66,3 +66,44 @@ def test_partition_is_contiguous_and_balanced():
         counts = [int(vd.shard_mask(sc.pt, sc.Np, r, world).sum()) for r in range(world)]
         assert sum(counts) == sc.No
         assert max(counts) - min(counts) <= 2 * 8 + sc.No // (50 * world)
+
+
+def _match_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from visual_slam_amd import dist as vd
+    from visual_slam_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d0, d1 = synth.make_descriptors(300, 280, seed=4)
+    d0[200] = d0[17]                                          # a tie across the shard boundary
+    bounds = [0, 130, 300]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    dm = orc.distance_matrix(d0[lo:hi], d1)                   # this rank's rows, all columns
+    keys = torch.from_numpy(vd.column_keys(dm, lo))
+    dist.all_reduce(keys, op=dist.ReduceOp.MIN)               # the exchange step of the sharded matcher
+    out[rank] = vd.matches_from_keys(dm, lo, keys.numpy(), 0.9)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_matcher_keys_reduce_to_the_whole_pair():
+    """World 2 over gloo: packed column keys + MIN all-reduce reproduce twoWayMatching of the whole
+    pair (the oracle), first-minimum ties included."""
+    from oracle import oracle as orc
+    from visual_slam_amd import synth
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_match_worker, args=(world, port, out), nprocs=world, join=True)
+    d0, d1 = synth.make_descriptors(300, 280, seed=4)
+    d0[200] = d0[17]
+    wi, wj, wd = orc.two_way_matching(d0, d1, 0.9)
+    gi = np.concatenate([out[0][0], out[1][0]]); gj = np.concatenate([out[0][1], out[1][1]])
+    gd = np.concatenate([out[0][2], out[1][2]])
+    assert len(wi) > 50 and np.array_equal(gi, wi) and np.array_equal(gj, wj)
+    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32))

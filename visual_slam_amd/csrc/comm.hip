@@ -68,6 +68,14 @@ namespace vs {
 int comm_rank(const vs_comm *c) { return c->rank; }
 int comm_world(const vs_comm *c) { return c->world; }
 
+int comm_allreduce_min_u64(vs_comm *c, unsigned long long *buf, int64_t n, hipStream_t s)
+{
+    VS_CHECK(c && c->comm, VS_ERR_STATE, "communicator not initialised");
+    if (n <= 0) return VS_OK;
+    VS_RCCL(g_api.AllReduce(buf, buf, (size_t)n, ncclUint64, ncclMin, c->comm, s));
+    return VS_OK;
+}
+
 int comm_allreduce(vs_comm *c, double *buf, int64_t n, bool take_max, hipStream_t s)
 {
     VS_CHECK(c && c->comm, VS_ERR_STATE, "communicator not initialised");

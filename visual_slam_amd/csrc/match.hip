@@ -821,12 +821,63 @@ second_scan_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
     }
 }
 
+// Row-sharded pair: packed key (exact distance bits, global row) of every column's nearest row
+// among this rank's rows; the element-wise minimum of the ranks' keys is the column's nearest
+// row of the whole frame (equal distances: the smaller row, i.e. the first minimum).  One wave
+// per 64 columns.
+template <bool MASKED>
+__global__ void __launch_bounds__(64)
+column_key_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+                  const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
+                  const int2 *__restrict__ xy1, int n0_pad, int n1_pad,
+                  const int *__restrict__ idx1, int row0, unsigned long long *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) float tA[64 * kPanelStride];
+    __shared__ __attribute__((aligned(16))) float tB[64 * kPanelStride];
+    __shared__ const float *pA[64];
+    __shared__ const float *pB[64];
+    const int pair = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 64 + lane;
+    const int n0 = dims[pair].n0, n1 = dims[pair].n1;
+    if (blockIdx.x * 64 >= n1) return;
+    int r = -1;
+    if (j < n1) r = idx1[(int64_t)pair * n1_pad + j];
+    const bool have = r >= 0 && r < n0;
+    if (!__ballot(have)) {
+        if (j < n1) keys[(int64_t)pair * n1_pad + j] = ~0ull;
+        return;
+    }
+    bool masked = false;
+    if (MASKED && have) masked = stereo_masked(xy0[(int64_t)pair * n0_pad + r], xy1[(int64_t)pair * n1_pad + j]);
+    pA[lane] = d0 + ((int64_t)pair * n0_pad + (have ? r : 0)) * kD;
+    pB[lane] = d1 + ((int64_t)pair * n1_pad + (have ? j : 0)) * kD;
+    __syncthreads();
+    const double acc = panel_dot64<false>(pA, pB, tA, tB, lane);
+    const float d = masked ? 1.0f : distance_from_dot(acc);
+    if (j < n1)
+        keys[(int64_t)pair * n1_pad + j] = have ? ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(row0 + r) : ~0ull;
+}
+
+// After the minimum over ranks: idx1[j] = (global nearest row) - row0, which equals a local row
+// index exactly when the winner lives on this rank.
+__global__ void apply_keys_kernel(const PairDims *__restrict__ dims, int n1_pad,
+                                  const unsigned long long *__restrict__ keys, int row0, int *__restrict__ idx1)
+{
+    const int pair = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= dims[pair].n1) return;
+    const unsigned long long k = keys[(int64_t)pair * n1_pad + j];
+    idx1[(int64_t)pair * n1_pad + j] = k == ~0ull ? -1 : (int)(unsigned)(k & 0xffffffffull) - row0;
+}
+
 // Mutual check, threshold (and optional ratio test), ordered compaction.  One workgroup per pair.
+// row0 is added to the row numbers written out (0 unless the pair is row-sharded).
 __global__ void __launch_bounds__(1024)
 compact_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
                const int *__restrict__ idx0, const int *__restrict__ idx1,
                const float *__restrict__ dist0, const float *__restrict__ second0, float nn_thresh,
-               float ratio, int *__restrict__ out_i, int *__restrict__ out_j,
+               float ratio, int row0, int *__restrict__ out_i, int *__restrict__ out_j,
                float *__restrict__ out_d, int *__restrict__ out_n)
 {
     __shared__ int wave_tot[16];
@@ -855,7 +906,7 @@ compact_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
         for (int w = 0; w < wave; w++) off += wave_tot[w];
         if (keep) {
             const int64_t o = (int64_t)pair * n0_pad + off + before;
-            out_i[o] = i; out_j[o] = j; out_d[o] = d;
+            out_i[o] = row0 + i; out_j[o] = j; out_d[o] = d;
         }
         __syncthreads();
         if (tid == 0) { int s = 0; for (int w = 0; w < 16; w++) s += wave_tot[w]; base_s += s; }
@@ -892,6 +943,11 @@ struct vs_matcher {
     DevBuf<float> dist0, dist1, second0, out_d;
     DevBuf<int> idx0, idx1, rescan_list, rescan_count, out_i, out_j, out_n;
     DevBuf<int> sec_idx, sec_list;      // ratio test: second-best column per row, rows that need the exact scan
+    // row-sharded pairs: packed column keys and how their minimum over ranks is taken
+    DevBuf<unsigned long long> keys;
+    vs_comm *comm = nullptr;
+    vs_allreduce_min_u64_fn min_fn = nullptr;
+    void *min_user = nullptr;
 };
 
 extern "C" {
@@ -991,8 +1047,17 @@ struct MatchView {
 
 // The matcher pipeline on pairs [0, n_pairs) of `v`: scores + fused top-2, merge, exact
 // re-decisions, mutual check + compaction.  Launches only; allocates nothing.
+// How a row-sharded run combines its column keys across ranks (nullptr for a whole pair).
+struct ShardCtx {
+    int row0;
+    unsigned long long *keys;       // n_pairs x n1_pad
+    vs_comm *comm;
+    vs_allreduce_min_u64_fn fn;
+    void *user;
+};
+
 static int run_match(const MatchView &v, int n_pairs, bool masked, float nn_thresh, float ratio,
-                     hipStream_t s, hipEvent_t *prof_ev)
+                     hipStream_t s, hipEvent_t *prof_ev, const ShardCtx *shard = nullptr)
 {
     auto mark = [&](int i) { if (prof_ev) (void)hipEventRecord(prof_ev[i], s); };
     const int r0 = v.n0_pad, r1 = v.n1_pad;
@@ -1019,13 +1084,39 @@ static int run_match(const MatchView &v, int n_pairs, bool masked, float nn_thre
                        v.rescan_count, want_second, v.sec_idx, v.sec_list);
     VS_TRY(launch_ok("merge_kernel"));
     mark(2);
+    if (masked)
+        hipLaunchKernelGGL(rescan_items_kernel<true>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
+                           v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
+                           v.col_part, v.stats, v.idx0, v.idx1);
+    else
+        hipLaunchKernelGGL(rescan_items_kernel<false>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
+                           v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
+                           v.col_part, v.stats, v.idx0, v.idx1);
+    if (shard) {
+        // the column nearest neighbours so far are over this rank's rows only
+        const dim3 kgrid(div_up(r1, 64), n_pairs);
+        if (masked)
+            hipLaunchKernelGGL(column_key_kernel<true>, kgrid, dim3(64), 0, s, v.d0, v.d1, v.dims, v.xy0, v.xy1,
+                               r0, r1, v.idx1, shard->row0, shard->keys);
+        else
+            hipLaunchKernelGGL(column_key_kernel<false>, kgrid, dim3(64), 0, s, v.d0, v.d1, v.dims, v.xy0, v.xy1,
+                               r0, r1, v.idx1, shard->row0, shard->keys);
+        VS_TRY(launch_ok("column_key_kernel"));
+        const int64_t nk = (int64_t)n_pairs * r1;
+        if (shard->comm) {
+            VS_TRY(comm_allreduce_min_u64(shard->comm, shard->keys, nk, s));
+        } else if (shard->fn) {
+            VS_HIP(hipStreamSynchronize(s));
+            VS_CHECK(shard->fn(shard->user, shard->keys, nk) == 0, VS_ERR_STATE, "the minimum all-reduce callback failed");
+        }
+        hipLaunchKernelGGL(apply_keys_kernel, dim3(div_up(r1, 256), n_pairs), dim3(256), 0, s, v.dims, r1,
+                           shard->keys, shard->row0, v.idx1);
+        VS_TRY(launch_ok("apply_keys_kernel"));
+    }
     {
         const dim3 dgrid(div_up(r0, 64), n_pairs);
         const int *sec = want_second ? v.sec_idx : nullptr;
         if (masked) {
-            hipLaunchKernelGGL(rescan_items_kernel<true>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
-                               v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
-                               v.col_part, v.stats, v.idx0, v.idx1);
             hipLaunchKernelGGL(mutual_distance_kernel<true>, dgrid, dim3(64), 0, s, v.d0, v.d1, v.dims,
                                v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0, sec, v.second0);
             if (want_second)
@@ -1033,9 +1124,6 @@ static int run_match(const MatchView &v, int n_pairs, bool masked, float nn_thre
                                    r0, r1, v.sec_list, v.rescan_count + 1, v.row_part, v.col_part, v.stats, v.idx0,
                                    v.idx1, v.second0);
         } else {
-            hipLaunchKernelGGL(rescan_items_kernel<false>, dim3(8192), dim3(64), 0, s, v.d0, v.d1, v.dims,
-                               v.xy0, v.xy1, r0, r1, v.rescan_list, v.rescan_count, v.row_part,
-                               v.col_part, v.stats, v.idx0, v.idx1);
             hipLaunchKernelGGL(mutual_distance_kernel<false>, dgrid, dim3(64), 0, s, v.d0, v.d1, v.dims,
                                v.xy0, v.xy1, r0, r1, v.idx0, v.idx1, v.dist0, sec, v.second0);
             if (want_second)
@@ -1047,7 +1135,7 @@ static int run_match(const MatchView &v, int n_pairs, bool masked, float nn_thre
     VS_TRY(launch_ok("exact kernels"));
     mark(3);
     hipLaunchKernelGGL(compact_kernel, dim3(n_pairs), dim3(1024), 0, s, v.dims, r0, r1, v.idx0, v.idx1,
-                       v.dist0, v.second0, nn_thresh, ratio, v.out_i, v.out_j, v.out_d, v.out_n);
+                       v.dist0, v.second0, nn_thresh, ratio, shard ? shard->row0 : 0, v.out_i, v.out_j, v.out_d, v.out_n);
     VS_TRY(launch_ok("compact_kernel"));
     mark(4);
     return VS_OK;
@@ -1075,6 +1163,37 @@ int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float 
     for (int p = 1; p < n_pairs; p++)
         VS_CHECK((bool)m->h_masked[p] == masked, VS_ERR_INVALID, "a batch must be all two-way or all stereo pairs");
     VS_TRY(run_match(handle_view(m), n_pairs, masked, nn_thresh, ratio, m->stream, m->prof_ev));
+    m->ran = true;
+    return VS_OK;
+}
+
+int vs_matcher_set_comm(vs_matcher_handle m, vs_comm_handle c)
+{
+    VS_CHECK(m != nullptr, VS_ERR_INVALID, "null handle");
+    m->comm = c;
+    return VS_OK;
+}
+
+int vs_matcher_set_min_allreduce(vs_matcher_handle m, vs_allreduce_min_u64_fn fn, void *user)
+{
+    VS_CHECK(m != nullptr, VS_ERR_INVALID, "null handle");
+    m->min_fn = fn;
+    m->min_user = user;
+    return VS_OK;
+}
+
+int vs_matcher_run_sharded(vs_matcher_handle m, int32_t n_pairs, int32_t row0, float nn_thresh, float ratio)
+{
+    VS_CHECK(m != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(n_pairs > 0 && n_pairs <= m->max_pairs, VS_ERR_INVALID, "n_pairs %d out of range (1..%d)", n_pairs, m->max_pairs);
+    VS_CHECK(row0 >= 0, VS_ERR_INVALID, "negative first row");
+    bool masked = m->h_masked[0];
+    for (int p = 1; p < n_pairs; p++)
+        VS_CHECK((bool)m->h_masked[p] == masked, VS_ERR_INVALID, "a batch must be all two-way or all stereo pairs");
+    const size_t nk = (size_t)m->max_pairs * m->n1_pad;
+    if (m->keys.n < nk) VS_TRY(m->keys.alloc(nk));
+    const ShardCtx shard{ row0, m->keys.p, m->comm, m->comm ? nullptr : m->min_fn, m->min_user };
+    VS_TRY(run_match(handle_view(m), n_pairs, masked, nn_thresh, ratio, m->stream, m->prof_ev, &shard));
     m->ran = true;
     return VS_OK;
 }

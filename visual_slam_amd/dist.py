@@ -61,3 +61,31 @@ def allreduce_sum_(array, group=None):
     t = torch.from_numpy(array)
     dist.all_reduce(t, group=group)
     return array
+
+
+def column_keys(dist_local, row0):
+    """Packed (distance bits, global row) key of every column's nearest row among the rows of one
+    row shard of a frame pair (dist_local: float32 n0_local x n1).  The element-wise minimum of the
+    shards' keys names the column's nearest row of the whole frame, equal distances resolving to
+    the smaller row (the reference's first minimum, src/core/superpoint_frontend.cc:197-203).
+    Same key as the device path's column_key_kernel; no rows -> the largest key."""
+    import numpy as np
+    d = np.ascontiguousarray(dist_local, dtype=np.float32)
+    if d.shape[0] == 0:
+        return np.full(d.shape[1], np.iinfo(np.int64).max, np.int64)
+    r = d.argmin(axis=0)                                     # first minimum
+    bits = d[r, np.arange(d.shape[1])].view(np.uint32).astype(np.int64)
+    return (bits << 32) | (r.astype(np.int64) + int(row0))
+
+
+def matches_from_keys(dist_local, row0, keys, nn_thresh):
+    """This shard's matches (global i, j, d) given the reduced column keys."""
+    import numpy as np
+    d = np.ascontiguousarray(dist_local, dtype=np.float32)
+    if d.shape[0] == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32)
+    j = d.argmin(axis=1)
+    i = np.arange(d.shape[0])
+    best = d[i, j]
+    keep = ((keys[j] & 0xffffffff) == i + int(row0)) & (best < nn_thresh)
+    return i[keep] + int(row0), j[keep], best[keep]

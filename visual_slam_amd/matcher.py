@@ -61,6 +61,31 @@ class Matcher:
     def run(self, n_pairs, nn_thresh=2.0, ratio=1.0):
         check(self.lib.vs_matcher_run(self.h, int(n_pairs), C.c_float(nn_thresh), C.c_float(ratio)))
 
+    def set_comm(self, comm):
+        """vs_matcher_set_comm: comm = a vs_comm handle (ctypes void pointer) or None."""
+        check(self.lib.vs_matcher_set_comm(self.h, comm))
+
+    def set_min_allreduce(self, fn):
+        """vs_matcher_set_min_allreduce: fn(device_address, n) must leave the element-wise minimum
+        over the ranks of the n uint64 at that device address in place."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+        def thunk(_user, buf, n):
+            try:
+                fn(int(buf), int(n))
+                return 0
+            except Exception:            # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._min_cb = proto(thunk)      # keep the callback object alive
+        check(self.lib.vs_matcher_set_min_allreduce(self.h, self._min_cb, None))
+
+    def run_sharded(self, n_pairs, row0, nn_thresh=2.0, ratio=1.0):
+        """vs_matcher_run_sharded: this handle holds rows row0.. of desc0 and all of desc1."""
+        check(self.lib.vs_matcher_run_sharded(self.h, int(n_pairs), int(row0), C.c_float(nn_thresh),
+                                              C.c_float(ratio)))
+
     def profile_run(self, n_pairs, nn_thresh=2.0, ratio=1.0, iters=5):
         """Average ms of [dot+top2, merge, exact+rescan, compact, total] (HIP events)."""
         ms = np.zeros(5, np.float32)

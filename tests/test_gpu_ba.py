@@ -95,14 +95,31 @@ def test_medium_problem_with_many_work_items(orc):
     assert abs(cost - ref.cost()) < 1e-11 * cost
 
 
-def test_unstaged_cameras_path(orc):
-    sc = synth.make_ba_scene(600, 3000, 4, band=16, seed=12)     # > 384 cameras: no LDS staging
-    ref, gpu = both(orc, sc)
+@pytest.mark.parametrize("lds_cameras", [True, False])
+def test_mid_size_camera_paths(orc, monkeypatch, lds_cameras):
+    """600 cameras, landmark ids at random: too many cameras for the per-workgroup LDS copy, no
+    short camera range per workgroup.  Default: every camera in the LDS of one persistent workgroup
+    per CU (landmark_lds_kernel, backsub_lds_kernel); with that switched off, camera records
+    gathered from L2.  Reduced system, LM step (Huber edge active) and the motion-only step
+    against the oracle."""
+    if not lds_cameras:
+        monkeypatch.setenv("VS_BA_NO_LDS_CAMS", "1")
+    sc = synth.make_ba_scene(600, 3000, 4, band=16, seed=12)
+    sc.uv = sc.uv.copy()
+    sc.uv[0] += 500.0                       # |r| > 100: Huber region of the first edge
+    ref, gpu = both(orc, sc, huber_a=100.0)
     dc = np.full(6 * sc.Nc, 0.5); dp = np.full(3 * sc.Np, 0.5)
     s = ref.schur(dc=dc, dp=dp)
     gpu.linearize(dc, dp)
-    S, rhs, _ = dense_from(gpu)
-    assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10
+    S, rhs, cost = dense_from(gpu)
+    assert rel(S, s["S"]) < 1e-10 and rel(rhs, s["rhs"]) < 1e-10 and abs(cost - ref.cost()) < 1e-11 * cost
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert rc == 0 and rel(d1, d0) < 1e-6 and rel(p1, p0) < 1e-6 and abs(m1 - m0) < 1e-8 * abs(m0)
+    ref2, gpu2 = both(orc, sc, fix_points=True)
+    rc, d0, _, m0, _, _ = ref2.lm_step(1e4)
+    d1, p1, m1 = gpu2.lm_step(1e4)
+    assert rc == 0 and rel(d1, d0) < 1e-9 and abs(m1 - m0) < 1e-9 * abs(m0) and not p1.any()
 
 
 def test_camera_range_staging_path(orc):

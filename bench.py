@@ -262,6 +262,33 @@ def bench_ba_shape(name, torch, steps=20):
                               algorithmic_bytes=int(alg)))
 
 
+def bench_solve_small():
+    """Whole vs_ba_solve runs at the reference's own operating point (config 1: 10 keyframes x 500
+    points, the call order of Tracking::solveCamera / solvePoints, src/core/tracking.cc:79-163), and
+    at config 2 (the CPU oracle's LM loop on the same problems: cpu_baseline.solve)."""
+    from visual_slam_amd import synth
+    from visual_slam_amd.ba import BAProblem
+    out = {}
+    for name in ("c1", "c2"):
+        sc = synth.make_ba_config(name, seed=0)
+        for fix in (True, False):
+            pts = sc.pts_gt if fix else sc.pts0
+            gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, pts, sc.cam, sc.pt, sc.uv, fix_points=fix)
+            gpu.solve()                                         # warm-up
+            ts = []
+            for _ in range(5):
+                gpu.set_cameras(sc.t0, sc.rpy0)
+                gpu.set_points(pts)
+                t0 = time.perf_counter()
+                g = gpu.solve()
+                ts.append(time.perf_counter() - t0)
+            gpu.close()
+            rec = dict(gpu_ms=float(np.median(ts)) * 1e3, iterations=int(g["iterations"]),
+                       final_cost=float(g["final_cost"]))
+            out["%s_%s" % (name, "motion_only" if fix else "full")] = rec
+    return out
+
+
 def bench_match(args, rank, world, dist, torch, n=4096, total_pairs=64):
     from visual_slam_amd import matcher as vm
     pairs = max(1, total_pairs // world)
@@ -465,6 +492,18 @@ def cpu_baseline(name):
                                    schur_route=dict(value=c2.No / dt_sc, seconds=dt_sc,
                                                     sample="median of %d vo_lm_step passes at c2 (Schur + dense "
                                                            "Cholesky + back-substitution)" % passes))
+    # whole LM solves at the reference's own operating point (config 1) and at config 2, one core
+    out["solve"] = {}
+    for nm in ("c1", "c2"):
+        s_ = synth.make_ba_config(nm, seed=0)
+        for fix in (True, False):
+            pts = s_.pts_gt if fix else s_.pts0
+            ref = orc.Problem(s_.K, s_.t0, s_.rpy0, pts, s_.cam, s_.pt, s_.uv, fix_points=fix)
+            t0 = time.perf_counter()
+            r = ref.solve()
+            out["solve"]["%s_%s" % (nm, "motion_only" if fix else "full")] = dict(
+                cpu_ms=(time.perf_counter() - t0) * 1e3, iterations=int(r["iterations"]), final_cost=float(r["final_cost"]),
+                cores=1, kind="port", sample="one vo_solve run (LM loop of the oracle)")
     d0, d1 = synth.make_descriptors(4096, 4096, seed=0)
     dm1 = _median_time(lambda: orc.two_way_matching(d0, d1, 0.7), 3, warm=0)
     dmn = _median_time(lambda: orc.two_way_matching_mt(threads, d0, d1, 0.7), 5)
@@ -574,6 +613,7 @@ def main():
             for nm in ("c2", "c4", "c5shard", "c5"):
                 extra[nm] = bench_ba_shape(nm, torch)
             extra["tracking"] = bench_tracking(torch)
+            extra["solve"] = bench_solve_small()
     if rank == 0:
         line = {
             "metric": "BA observations/sec (residual+J+Schur) & SuperPoint matches/sec, 1\u20138 GPU",

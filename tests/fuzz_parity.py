@@ -1,0 +1,82 @@
+"""Randomised parity sweep on the GPU (a script, not collected by pytest: python3 tests/fuzz_parity.py [seed] [n]).
+Bundle adjustment: random camera counts (all three landmark-kernel camera paths), landmark counts,
+track lengths, bands, keyframe / random landmark order, fixed points, Huber first edge, shards;
+reduced system and LM step against the CPU oracle.  Matcher: random sizes, ratio test, stereo
+mask, row shards; indices and distance bits against the CPU oracle."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as orc
+from visual_slam_amd import synth
+from visual_slam_amd.ba import BAProblem
+from visual_slam_amd import matcher as vm
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+rng = np.random.default_rng(seed)
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+bad = 0
+for case in range(n_cases):
+    Nc = int(rng.choice([2, 3, 7, 10, 33, 64, 150, 279, 280, 400, 700, 1228, 1229, 1500]))
+    k = int(rng.integers(2, min(Nc, 9) + 1))
+    band = int(rng.integers(k, min(Nc, 40) + 1))
+    Np = int(rng.integers(20, 3000))
+    sc = synth.make_ba_scene(Nc, Np, k, band=band, seed=int(rng.integers(1 << 30)), k_jitter=min(2, k - 2))
+    if rng.random() < 0.4:
+        sc = synth.landmarks_in_keyframe_order(sc)
+    fix = bool(rng.random() < 0.25)
+    hub = 100.0 if rng.random() < 0.3 else 0.0
+    if hub:
+        sc.uv = sc.uv.copy(); sc.uv[0] += 400.0
+    ref = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, huber_a=hub, fix_points=fix)
+    gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, huber_a=hub, fix_points=fix)
+    dc = np.full(6 * Nc, 0.5); dp = np.full(3 * Np, 0.5)
+    s = ref.schur(dc=dc, dp=dp)
+    gpu.linearize(dc, dp)
+    S, rhs, cost = gpu.reduced_system_dense()
+    e1, e2 = rel(S, s["S"]), rel(rhs, s["rhs"])
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    e3, e4 = rel(d1, d0), abs(m1 - m0) / max(abs(m0), 1e-300)
+    # two shards add up
+    world = int(rng.integers(2, 4))
+    tot = 0
+    for r in range(world):
+        part = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, huber_a=hub, fix_points=fix, rank=r, world=world)
+        part.linearize(None, dp)
+        tot = tot + part.reduced_system()[2]
+        part.close()
+    gpu.linearize(None, dp)
+    e5 = rel(tot, gpu.reduced_system()[2])
+    gpu.close()
+    ok = e1 < 1e-9 and e2 < 1e-9 and rc == 0 and e3 < 1e-5 and e4 < 1e-7 and e5 < 1e-11
+    bad += not ok
+    print("BA  case %2d Nc %4d Np %4d k %d band %2d fix %d huber %d : S %.1e rhs %.1e step %.1e mcc %.1e shards %.1e %s"
+          % (case, Nc, Np, k, band, fix, hub > 0, e1, e2, e3, e4, e5, "ok" if ok else "MISMATCH"), flush=True)
+
+for case in range(n_cases):
+    n0, n1 = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+    d0, d1 = synth.make_descriptors(n0, n1, seed=int(rng.integers(1 << 30)), duplicates=int(rng.integers(0, 4)))
+    ratio = float(rng.choice([1.0, 0.8, 0.95]))
+    th = float(rng.choice([2.0, 0.9, 0.7]))
+    stereo = rng.random() < 0.3
+    if stereo:
+        xy0, xy1 = synth.make_keypoints(n0, seed=case), synth.make_keypoints(n1, seed=case + 999)
+        want = orc.stereo_matching(d0, xy0, d1, xy1, th, ratio)
+        got = vm.stereo(d0, xy0, d1, xy1, th, ratio)
+    else:
+        want = orc.two_way_matching(d0, d1, th, ratio)
+        got = vm.two_way(d0, d1, th, ratio)
+    ok = (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+          and np.array_equal(got[2].view(np.uint32), want[2].view(np.uint32)))
+    bad += not ok
+    print("MAT case %2d %4d x %4d thresh %.2f ratio %.2f stereo %d : %d matches %s"
+          % (case, n0, n1, th, ratio, stereo, len(want[0]), "ok" if ok else "MISMATCH"), flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)

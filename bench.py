@@ -392,6 +392,45 @@ def bench_match(args, rank, world, dist, torch, n=4096, total_pairs=64):
     return out
 
 
+def bench_match_one_pair_sharded(args, rank, world, dist, torch, comm, n=4096):
+    """ONE 4096 x 4096 frame pair split by query rows over the ranks (vs_matcher_run_sharded): every
+    rank holds n / world rows of desc0 and all of desc1; the column nearest neighbours are combined
+    by the library's minimum all-reduce of packed keys on the matcher's stream."""
+    from visual_slam_amd import matcher as vm
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4321)                                   # the same pair on every rank
+    d0 = torch.randn(n, 256, device="cuda", generator=g)
+    d0 = d0 / d0.norm(dim=1, keepdim=True)
+    d1 = d0[torch.randperm(n, device="cuda", generator=g)] + (0.3 / 16.0) * torch.randn(n, 256, device="cuda", generator=g)
+    d1 = (d1 / d1.norm(dim=1, keepdim=True)).contiguous()
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    mine = d0[lo:hi].contiguous()
+    mt = vm.Matcher(1, max(hi - lo, 1), n)
+    mt.set_stream(torch.cuda.current_stream().cuda_stream)
+    mt.set_pair(0, (mine.data_ptr(), hi - lo), (d1.data_ptr(), n))
+    mt.set_comm(comm)
+    steps = max(10, args.steps // 10)
+    for _ in range(3):
+        mt.run_sharded(1, lo, 0.7)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        mt.run_sharded(1, lo, 0.7)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    per = float(tt.item()) / steps
+    n_local = len(mt.matches(0)[0])
+    cnt = torch.tensor([n_local], device="cuda", dtype=torch.int64)
+    dist.all_reduce(cnt)
+    mt.close()
+    return dict(n0=n, n1=n, ranks=world, ms_per_pair=per * 1e3, query_rows_per_s=n / per, matches=int(cnt.item()),
+                note="one pair, query rows split over the ranks, packed-key minimum all-reduce (32 KB) per pair")
+
+
 def bench_tracking(torch):
     """Per-frame tracking helpers at frame scale (host buffers in, host buffers out)."""
     from visual_slam_amd import synth
@@ -609,6 +648,8 @@ def main():
     extra = {}
     if not args.no_extra:
         extra["matcher"] = bench_match(args, rank, world, dist, torch)
+        if comm is not None:
+            extra["matcher_one_pair_sharded"] = bench_match_one_pair_sharded(args, rank, world, dist, torch, comm)
         if rank == 0 and world == 1:
             for nm in ("c2", "c4", "c5shard", "c5"):
                 extra[nm] = bench_ba_shape(nm, torch)

@@ -241,6 +241,19 @@ def test_wide_band_solver_matches_oracle_and_dense(orc, monkeypatch):
     monkeypatch.delenv("VS_BA_SOLVER")
 
 
+@pytest.mark.parametrize("Nc,Np,k,band,seed", [(10, 1513, 4, 4, 41), (30, 2000, 3, 3, 42), (48, 2500, 2, 2, 43),
+                                               (63, 3000, 3, 5, 44), (12, 800, 2, 3, 45)])
+def test_short_chains_with_a_narrow_band(orc, Nc, Np, k, band, seed):
+    """Few cameras whose pairs stay within one to four frames of each other: the reduced system's
+    half-bandwidth (11 to 29) is narrower than one 32-column panel of the band factorisation, and
+    the chain is too short for cyclic reduction.  LM step against the oracle's dense solve."""
+    sc = synth.make_ba_scene(Nc, Np, k, band=band, seed=seed, k_jitter=0)
+    ref, gpu = both(orc, sc)
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert rc == 0 and rel(d1, d0) < 1e-6 and rel(p1, p0) < 1e-6 and abs(m1 - m0) < 1e-8 * abs(m0)
+
+
 @pytest.mark.parametrize("Nc,Np,k,band,seed", [(200, 3000, 4, 8, 31), (333, 4000, 5, 20, 32), (70, 1500, 4, 16, 33),
                                                (64, 1200, 4, 12, 34), (1000, 20000, 4, 16, 35)])
 def test_cyclic_reduction_matches_band_cholesky_and_oracle(orc, monkeypatch, Nc, Np, k, band, seed):

@@ -618,7 +618,10 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         const int n = 6 * Nc;
         // band storage when the camera pairs stay close to the diagonal (keyframes in time
         // order), dense otherwise
-        const int band = 6 * h->max_pair_gap + 5;
+        // (at least a panel and a half wide: the one-workgroup band factorisation walks 32-column
+        // panels and keeps the next panel's diagonal block inside the window; a wider band than the
+        // pattern needs only adds stored zeros)
+        const int band = std::max(6 * h->max_pair_gap + 5, kNB + 15);
         bool banded = (int64_t)(band + 1) * 2 <= n;
         if (const char *e = getenv("VS_BA_SOLVER")) banded = banded && strcmp(e, "dense") != 0;   // test knob
         // long chains of cameras: block cyclic reduction, parallel over the chain (bcr_solve.h)

@@ -14,6 +14,7 @@ from visual_slam_amd import matcher as vm
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+small = len(sys.argv) > 3 and sys.argv[3] == "small"     # many small shapes (fast): edge cases of the small-system paths
 rng = np.random.default_rng(seed)
 
 
@@ -23,10 +24,11 @@ def rel(a, b):
 
 bad = 0
 for case in range(n_cases):
-    Nc = int(rng.choice([2, 3, 7, 10, 33, 64, 150, 279, 280, 400, 700, 1228, 1229, 1500]))
+    Nc = int(rng.choice([2, 3, 4, 5, 7, 10, 16, 21, 33, 48, 64, 65, 90, 150]) if small else
+             rng.choice([2, 3, 7, 10, 33, 64, 150, 279, 280, 400, 700, 1228, 1229, 1500]))
     k = int(rng.integers(2, min(Nc, 9) + 1))
     band = int(rng.integers(k, min(Nc, 40) + 1))
-    Np = int(rng.integers(20, 3000))
+    Np = int(rng.integers(5, 600)) if small else int(rng.integers(20, 3000))
     sc = synth.make_ba_scene(Nc, Np, k, band=band, seed=int(rng.integers(1 << 30)), k_jitter=min(2, k - 2))
     if rng.random() < 0.4:
         sc = synth.landmarks_in_keyframe_order(sc)
@@ -61,14 +63,24 @@ for case in range(n_cases):
         part.close()
     gpu.linearize(None, dp)
     e5 = rel(tot, gpu.reduced_system()[2])
+    # whole LM loop: same iteration count, termination and final cost
+    note = ""
+    if small:
+        o0, o1 = ref.solve(), gpu.solve()
+        if o0["iterations"] != o1["iterations"] or o0["termination"] != o1["termination"]:
+            note = " (solve: %d/%d iterations, termination %d/%d)" % (o0["iterations"], o1["iterations"], o0["termination"], o1["termination"])
+        # (under-constrained scenes make the LM trajectory sensitive to the last bits of every step:
+        # after dozens of iterations the two loops agree to a few digits only; flag real differences)
+        if abs(o0["final_cost"] - o1["final_cost"]) > 1e-3 * max(abs(o0["final_cost"]), 1e-9 * abs(o0["initial_cost"])):
+            note += " SOLVE COST %.9g vs %.9g" % (o0["final_cost"], o1["final_cost"])
     gpu.close()
-    ok = e1 < 1e-9 and e2 < 1e-9 and rc == 0 and e3 < 1e-5 and e4 < 1e-7 and e5 < 1e-11
+    ok = e1 < 1e-9 and e2 < 1e-9 and rc == 0 and e3 < 1e-5 and e4 < 1e-7 and e5 < 1e-11 and "SOLVE COST" not in note
     bad += not ok
     print("BA  case %2d Nc %4d Np %4d k %d band %2d fix %d huber %d : S %.1e rhs %.1e step %.1e mcc %.1e shards %.1e %s"
-          % (case, Nc, Np, k, band, fix, hub > 0, e1, e2, e3, e4, e5, "ok" if ok else "MISMATCH"), flush=True)
+          % (case, Nc, Np, k, band, fix, hub > 0, e1, e2, e3, e4, e5, ("ok" if ok else "MISMATCH") + note), flush=True)
 
 for case in range(0 if os.environ.get('FUZZ_BA_ONLY') else n_cases):
-    n0, n1 = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+    n0, n1 = (int(rng.integers(1, 200)), int(rng.integers(1, 200))) if small else (int(rng.integers(1, 1500)), int(rng.integers(1, 1500)))
     d0, d1 = synth.make_descriptors(n0, n1, seed=int(rng.integers(1 << 30)), duplicates=int(rng.integers(0, 4)))
     ratio = float(rng.choice([1.0, 0.8, 0.95]))
     th = float(rng.choice([2.0, 0.9, 0.7]))

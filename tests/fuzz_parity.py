@@ -23,6 +23,31 @@ def rel(a, b):
 
 
 bad = 0
+if len(sys.argv) > 3 and sys.argv[3] == "thresholds":
+    # deterministic grid around the solver-selection thresholds: chain lengths of 3-5 blocks of 16 / 32
+    # cameras, camera-pair gaps around 16 and 32 (block size 16 / 32 / too wide for cyclic reduction),
+    # band windows around 224 and 448 rows
+    grid = [(Nc, band) for Nc in (47, 48, 49, 63, 64, 65, 80, 96, 97, 127, 128, 129, 160)
+            for band in (2, 8, 15, 16, 17, 18, 31, 32, 33, 34, 37, 38, 39, 45, 60, 75, 76)]
+    for case, (Nc, band) in enumerate(grid):
+        if band > Nc:
+            continue
+        sc = synth.make_ba_scene(Nc, 1500, min(4, band), band=band, seed=1000 + case, k_jitter=0)
+        ref = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+        gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+        rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+        try:
+            d1, p1, m1 = gpu.lm_step(1e4)
+            e3, e4 = rel(d1, d0), abs(m1 - m0) / max(abs(m0), 1e-300)
+            ok = rc == 0 and e3 < 1e-5 and e4 < 1e-7
+        except Exception as e:                     # noqa: BLE001 (report and go on)
+            e3 = e4 = float("nan"); ok = False
+            print("    error:", e)
+        gpu.close()
+        bad += not ok
+        print("GRID case %3d Nc %4d band %3d : step %.1e mcc %.1e %s" % (case, Nc, band, e3, e4, "ok" if ok else "MISMATCH"), flush=True)
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
 for case in range(n_cases):
     Nc = int(rng.choice([2, 3, 4, 5, 7, 10, 16, 21, 33, 48, 64, 65, 90, 150]) if small else
              rng.choice([2, 3, 7, 10, 33, 64, 150, 279, 280, 400, 700, 1228, 1229, 1500]))

@@ -88,6 +88,8 @@ def bench_ba(args, rank, world, dist, torch, comm):
         if comm is not None:      # RCCL all-reduce enqueued by the library on the step's stream
             rc = lib.vs_comm_allreduce_sum(comm, C.c_void_p(ptr), C.c_int64(n), sptr)
             assert rc == 0
+        elif dist is not None and dist.get_backend() == "nccl":
+            dist.all_reduce(red)  # the library's communicator did not come up: torch's RCCL group, same stream
         elif dist is not None:    # rehearsal backend (gloo): summed on the host, copied back
             host = red.cpu()
             dist.all_reduce(host)
@@ -111,7 +113,7 @@ def bench_ba(args, rank, world, dist, torch, comm):
         sync()
         dt = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([dt], device="cuda" if comm is not None else "cpu", dtype=torch.float64)
+            tt = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
@@ -623,21 +625,34 @@ def main():
             torch.cuda.synchronize()
             if backend == "nccl":
                 # the library's own communicator: rank 0 makes the id, torch.distributed carries it
+                # (byte 128 of the message says whether rank 0 could make one).  Should the library's
+                # communicator not come up on every rank, all ranks drop to torch's RCCL group together.
                 lib = _lib.load()
-                ident = torch.zeros(128, dtype=torch.uint8)
+                ident = torch.zeros(129, dtype=torch.uint8)
                 if rank == 0:
                     buf = (C.c_char * 128)()
-                    _lib.check(lib.vs_comm_unique_id(buf))
-                    ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                    # VS_BENCH_NO_LIB_COMM=1 rehearses the fall-back
+                    if not os.environ.get("VS_BENCH_NO_LIB_COMM") and lib.vs_comm_unique_id(buf) == 0:
+                        ident[:128] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+                        ident[128] = 1
                 ident = ident.cuda()
                 dist.broadcast(ident, 0)
-                raw = bytes(ident.cpu().numpy().tobytes())
-                comm = C.c_void_p()
-                _lib.check(lib.vs_comm_create(C.byref(comm), rank, world, raw))
-                x = torch.ones(8, device="cuda", dtype=torch.float64)
-                _lib.check(lib.vs_comm_allreduce_sum(comm, C.c_void_p(x.data_ptr()), C.c_int64(8), None))
-                torch.cuda.synchronize()
-                assert float(x[0].item()) == float(world)
+                ident = ident.cpu()
+                ok = int(ident[128])
+                if ok:
+                    raw = bytes(ident[:128].numpy().tobytes())
+                    comm = C.c_void_p()
+                    x = torch.ones(8, device="cuda", dtype=torch.float64)
+                    ok = int(lib.vs_comm_create(C.byref(comm), rank, world, raw) == 0 and
+                             lib.vs_comm_allreduce_sum(comm, C.c_void_p(x.data_ptr()), C.c_int64(8), None) == 0)
+                    torch.cuda.synchronize()
+                    ok = int(ok and float(x[0].item()) == float(world))
+                flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    trace("library communicator unavailable (%s): using torch.distributed's RCCL group"
+                          % lib.vs_last_error_string().decode("utf-8", "replace"))
+                    comm = None
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)

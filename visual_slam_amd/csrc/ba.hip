@@ -81,6 +81,10 @@ struct vs_ba {
     double huber_a = 0.0;
     bool have_cams = false, have_pts = false, have_obs = false, linearized = false;
     bool have_scale = false;
+    // vs_ba_solve linearises an accepted point once, with the damping of the next step, and takes the
+    // gradient test from that pass: red/lmrec then already hold what the next step starts from
+    bool prelin = false;
+    double prelin_radius = 0.0;
     int rank = 0, world = 1;
     HuberObs hub{ -1, -1, -1, 0.0 };
     int max_pair_gap = 0;   // largest |a - b| over the camera pairs of the reduced system
@@ -112,7 +116,7 @@ struct vs_ba {
     DevBuf<unsigned char> cam_used, pt_used;
     DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
     DevBuf<real> scale_c, scale_p, lam_c, lam_c_user, lam_p_user, dcam, dpt, mcc_partial,
-        cand_partial, scalars, dense, linv, bcr_ws;
+        cand_partial, gmax_partial, scalars, dense, linv, bcr_ws;
     DevBuf<int> info;
 
     real *S_diag() { return red.p; }
@@ -452,7 +456,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     VS_HIP(hipStreamSynchronize(s));
     h->have_obs = true;
     h->linearized = false;
-    h->have_scale = false;
+    h->have_scale = false; h->prelin = false;
     return VS_OK;
 }
 
@@ -582,6 +586,26 @@ int cross_gpu_max(vs_ba *h, real *val)
 
 struct StepScalars { real mcc, xnorm2, snorm2, cost_new; };
 
+// Undamped pass at the handle's parameters with the Schur terms left out (only the cost, the
+// gradient, diag(U) and diag(V) are wanted), and the Jacobi scaling taken from it: the scaling of a
+// whole solve comes from the Jacobian at its first iterate.
+int unscaled_pass(vs_ba *h)
+{
+    PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
+    const bool fp = h->fix_points;
+    h->fix_points = true;
+    int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none, nullptr, true);
+    h->fix_points = fp;
+    VS_TRY(rc);
+    VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+    hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(6 * h->Nc, 256)), dim3(256), 0, h->stream, 6 * h->Nc, h->udiag(), h->scale_c.p);
+    hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(3 * (int64_t)h->Np, 256)), dim3(256), 0, h->stream, 3 * h->Np, h->Vdiag.p, h->scale_p.p);
+    VS_TRY(launch_check("jacobi_scale_kernel"));
+    h->have_scale = true;
+    h->prelin = false;
+    return VS_OK;
+}
+
 // One LM step at the handle's current parameters.  Leaves dcam/dpt and the candidate
 // parameters (t2,rpy2,pts2) on the device; fills sc (host).  *numeric_fail set when the reduced
 // system is not positive definite.
@@ -590,23 +614,13 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
 {
     hipStream_t s = h->stream;
     const int Nc = h->Nc, Np = h->Np;
-    if (!h->have_scale) {
-        // Jacobi scaling from the Jacobian at the first iterate
-        PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
-        const bool fp = h->fix_points;
-        h->fix_points = true;   // only diag(U), diag(V) are needed: skip the Schur terms
-        int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none, nullptr, true);
-        h->fix_points = fp;
-        VS_TRY(rc);
+    if (!h->have_scale) VS_TRY(unscaled_pass(h));
+    if (!(h->prelin && h->prelin_radius == radius)) {
+        PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)min_d, (real)max_d };
+        VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
         VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
-        hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(6 * Nc, 256)), dim3(256), 0, s, 6 * Nc, h->udiag(), h->scale_c.p);
-        hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(3 * (int64_t)Np, 256)), dim3(256), 0, s, 3 * Np, h->Vdiag.p, h->scale_p.p);
-        VS_TRY(launch_check("jacobi_scale_kernel"));
-        h->have_scale = true;
     }
-    PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)min_d, (real)max_d };
-    VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
-    VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+    h->prelin = false;   // the camera damping below changes the reduce buffer in place
     hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * Nc, 256)), dim3(256), 0, s, Nc, h->udiag(),
                        h->scale_c.p, (const real *)nullptr, (real)radius, (real)min_d, (real)max_d, h->lam_c.p, h->S_diag(),
                        h->rhs(), h->dcam.p, h->info.p);
@@ -704,8 +718,11 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
 
 int gradient_max(vs_ba *h, real *out)
 {
-    hipLaunchKernelGGL(gradient_max_kernel, dim3(1), dim3(256), 0, h->stream, (int64_t)6 * h->Nc, h->gc(),
-                       h->fix_points ? (int64_t)0 : 3 * (int64_t)h->Np, h->lmrec.p, h->scalars.p + 4);
+    const int64_t np = h->fix_points ? 0 : h->Np;
+    const int nb = (int)std::min<int64_t>(kGradMaxBlocks, div_up(std::max<int64_t>(6 * (int64_t)h->Nc, np), 256));
+    hipLaunchKernelGGL(gradient_max_kernel, dim3(nb), dim3(256), 0, h->stream, (int64_t)6 * h->Nc, h->gc(), np,
+                       h->lmrec.p, h->gmax_partial.p);
+    hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(64), 0, h->stream, nb, h->gmax_partial.p, h->scalars.p + 4);
     VS_TRY(launch_check("gradient_max_kernel"));
     VS_TRY(cross_gpu_max(h, h->scalars.p + 4));   // landmark gradients are local to a shard
     VS_HIP(hipMemcpyAsync(out, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, h->stream));
@@ -754,7 +771,7 @@ int vs_ba_create(vs_ba_handle *out, int32_t Nc, int32_t Np, int64_t No, double f
     A(h->lmrec.alloc((size_t)kRec * Np)); A(h->Vdiag.alloc(3 * (size_t)Np));
     A(h->hub_w.alloc(1)); A(h->scale_c.alloc(6 * (size_t)Nc)); A(h->scale_p.alloc(3 * (size_t)Np));
     A(h->lam_c.alloc(6 * (size_t)Nc)); A(h->dcam.alloc(6 * (size_t)Nc)); A(h->dpt.alloc(3 * (size_t)Np));
-    A(h->scalars.alloc(8)); A(h->info.alloc(1)); A(h->linv.alloc(kNB * kNB));
+    A(h->scalars.alloc(8)); A(h->info.alloc(1)); A(h->linv.alloc(kNB * kNB)); A(h->gmax_partial.alloc(kGradMaxBlocks));
     if (rc != VS_OK) { delete h; return rc; }
     *out = h;
     return VS_OK;
@@ -779,7 +796,7 @@ int vs_ba_set_cameras(vs_ba_handle h, const double *t, const double *rpy)
     VS_HIP(hipMemcpyAsync(h->t.p, t, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
     VS_HIP(hipMemcpyAsync(h->rpy.p, rpy, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
     VS_HIP(hipStreamSynchronize(h->stream));
-    h->have_cams = true; h->linearized = false; h->have_scale = false;
+    h->have_cams = true; h->linearized = false; h->have_scale = false; h->prelin = false;
     return VS_OK;
 }
 
@@ -788,7 +805,7 @@ int vs_ba_set_points(vs_ba_handle h, const double *xyz)
     VS_CHECK(h && xyz, VS_ERR_INVALID, "null argument");
     VS_HIP(hipMemcpyAsync(h->pts.p, xyz, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
     VS_HIP(hipStreamSynchronize(h->stream));
-    h->have_pts = true; h->linearized = false; h->have_scale = false;
+    h->have_pts = true; h->linearized = false; h->have_scale = false; h->prelin = false;
     return VS_OK;
 }
 
@@ -811,7 +828,7 @@ int vs_ba_set_fixed(vs_ba_handle h, int32_t fix_points)
 {
     VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
     h->fix_points = fix_points != 0;
-    h->linearized = false; h->have_scale = false;
+    h->linearized = false; h->have_scale = false; h->prelin = false;
     return VS_OK;
 }
 
@@ -1020,20 +1037,11 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
     double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
     int it = 0, term = 1, nsucc = 0, invalid = 0;
     double cost = 0.0, cost0 = 0.0;
-    h->have_scale = false;
-    // initial cost and gradient (unscaled, undamped)
-    {
-        PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
-        const bool fp = h->fix_points;
-        h->fix_points = true;
-        int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none);
-        h->fix_points = fp;
-        VS_TRY(rc);
-        VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
-        VS_HIP(hipMemcpyAsync(&cost, h->cost(), sizeof(real), hipMemcpyDeviceToHost, s));
-        VS_HIP(hipStreamSynchronize(s));
-        cost0 = cost;
-    }
+    // initial cost and gradient (unscaled, undamped); the same pass gives the Jacobi scaling
+    VS_TRY(unscaled_pass(h));
+    VS_HIP(hipMemcpyAsync(&cost, h->cost(), sizeof(real), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    cost0 = cost;
     if (h->No_global == 0) term = 0;
     else {
         real gmax = 0;
@@ -1066,14 +1074,13 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
                     if (f < 1.0 / 3.0) f = 1.0 / 3.0;
                     radius = std::min(radius / f, o.max_trust_region_radius);
                     decrease_factor = 2.0;
-                    // gradient at the accepted point
-                    PointDamping none{ nullptr, nullptr, 1.0, 0.0, 0.0 };
-                    const bool fp = h->fix_points;
-                    h->fix_points = true;
-                    int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none);
-                    h->fix_points = fp;
-                    VS_TRY(rc);
+                    // gradient at the accepted point, from the pass the next step starts from (the
+                    // gradient does not depend on the damping)
+                    PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)o.min_lm_diagonal, (real)o.max_lm_diagonal };
+                    VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
                     VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+                    h->prelin = true;
+                    h->prelin_radius = radius;
                     VS_TRY(gradient_max(h, &gmax));
                     if (gmax <= o.gradient_tolerance) { term = 0; break; }
                 } else {
@@ -1083,6 +1090,7 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
             }
     }
     h->linearized = false;
+    h->prelin = false;
     if (is_sharded(h) && !h->fix_points) {
         // every rank has updated only its own landmarks: zero the others and sum the shards
         hipLaunchKernelGGL(mask_points_kernel, dim3(div_up(3 * (int64_t)h->Np, 256)), dim3(256), 0, s, h->Np, h->pt_lo,

@@ -1360,20 +1360,27 @@ candidate_kernel(int Nc, int Np, int fix_points, const real *__restrict__ t,
     if (threadIdx.x == 0) { out_partial[2 * blockIdx.x] = s0; out_partial[2 * blockIdx.x + 1] = s1; }
 }
 
-// max |g| over camera gradient (6Nc) and, unless fix_points, the landmark gradients (3Np).
+// max |g| over the camera gradient (nc6 = 6 Nc values) and the gradients of np landmarks (np = 0
+// with fixed points; g_p sits at reals 9..11 of a landmark record): one partial maximum per
+// workgroup, grid-strided; max_of_kernel finishes.
+constexpr int kGradMaxBlocks = 2048;
 __global__ void __launch_bounds__(256)
-gradient_max_kernel(int64_t nc6, const real *__restrict__ gc, int64_t np3,
-                    const real *__restrict__ lmrec, real *__restrict__ out)
+gradient_max_kernel(int64_t nc6, const real *__restrict__ gc, int64_t np,
+                    const real *__restrict__ lmrec, real *__restrict__ partial)
 {
     __shared__ real red[4];
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     real m = 0;
-    for (int64_t i = threadIdx.x; i < nc6; i += 256) m = fmax(m, fabs(gc[i]));
-    for (int64_t i = threadIdx.x; i < np3; i += 256) m = fmax(m, fabs(lmrec[(i / 3) * kRec + 9 + i % 3]));
+    for (int64_t i = i0; i < nc6; i += stride) m = fmax(m, fabs(gc[i]));
+    for (int64_t j = i0; j < np; j += stride) {
+        const real *g = lmrec + j * kRec + 9;
+        m = fmax(fmax(m, fabs(g[0])), fmax(fabs(g[1]), fabs(g[2])));
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) *out = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
 }  // namespace vs

@@ -288,6 +288,22 @@ def bench_solve_small():
             rec = dict(gpu_ms=float(np.median(ts)) * 1e3, iterations=int(g["iterations"]),
                        final_cost=float(g["final_cost"]))
             out["%s_%s" % (name, "motion_only" if fix else "full")] = rec
+    # ten LM iterations of full BA at config 4 (the CPU oracle forms the dense reduced system there:
+    # no CPU figure beside it)
+    sc = synth.make_ba_config("c4", seed=0)
+    gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    gpu.solve(max_num_iterations=2)
+    ts = []
+    for _ in range(3):
+        gpu.set_cameras(sc.t0, sc.rpy0)
+        gpu.set_points(sc.pts0)
+        t0 = time.perf_counter()
+        g = gpu.solve(max_num_iterations=10)
+        ts.append(time.perf_counter() - t0)
+    gpu.close()
+    out["c4_full_10_iterations"] = dict(gpu_ms=float(np.median(ts)) * 1e3, iterations=int(g["iterations"]),
+                                        successful_steps=int(g["successful_steps"]),
+                                        initial_cost=float(g["initial_cost"]), final_cost=float(g["final_cost"]))
     return out
 
 

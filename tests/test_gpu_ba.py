@@ -182,6 +182,28 @@ def test_solve_matches_oracle(orc, fix_points):
     assert out1["final_cost"] < 0.2 * out1["initial_cost"]
 
 
+@pytest.mark.parametrize("fix_points", [True, False])
+@pytest.mark.parametrize("gtol", [1e1, 1e-1, 1e-3])
+def test_solve_stops_on_the_gradient_test(orc, fix_points, gtol):
+    # function and parameter tests off: the gradient test at an accepted point ends the solve (the
+    # library reads that test's result one step late and drops the step it had started meanwhile)
+    sc = synth.make_ba_config("c1", seed=12)
+    pts = sc.pts_gt if fix_points else sc.pts0
+    ref, gpu = both(orc, sc, pts=pts, fix_points=fix_points)
+    o = orc.DEFAULT_OPTS.copy()
+    o[0], o[7], o[8], o[9] = 30, 0.0, gtol, 0.0
+    out0 = ref.solve(o)
+    out1 = gpu.solve(max_num_iterations=30, function_tolerance=0.0, gradient_tolerance=gtol,
+                     parameter_tolerance=0.0)
+    assert out0["termination"] == 0 and out0["iterations"] < 30
+    for k in ("termination", "iterations", "successful_steps"):
+        assert out1[k] == out0[k], k
+    assert abs(out1["final_cost"] - out0["final_cost"]) < 1e-9 * out0["final_cost"]
+    assert abs(out1["radius"] - out0["radius"]) < 1e-9 * out0["radius"]
+    t, rpy = gpu.cameras()
+    assert rel(t, ref.t) < 1e-6 and rel(rpy, ref.rpy) < 1e-6 and rel(gpu.points(), ref.pts) < 1e-6
+
+
 def test_huber_first_edge_active(orc):
     sc = synth.make_ba_config("c1", seed=8)
     sc.uv = sc.uv.copy()

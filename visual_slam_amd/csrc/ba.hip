@@ -118,6 +118,7 @@ struct vs_ba {
     DevBuf<real> scale_c, scale_p, lam_c, lam_c_user, lam_p_user, dcam, dpt, mcc_partial,
         cand_partial, gmax_partial, scalars, dense, linv, bcr_ws;
     DevBuf<int> info;
+    PinnedBuf<real> host_scalars;   // 16 reals: [0,8) step scalars, 8 gradient maximum, 9 cost
 
     real *S_diag() { return red.p; }
     real *S_off() { return red.p + (int64_t)Nc * 36; }
@@ -707,7 +708,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
                        h->cand_partial.p, want_candidate_cost ? h->n_lm_blocks : 0, h->cost_partial.p, h->info.p,
                        h->scalars.p);
     VS_TRY(launch_check("step_scalars_kernel"));
-    real host8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    real *host8 = h->host_scalars.p;
     VS_TRY(cross_gpu_sum(h, h->scalars.p, 4));
     VS_HIP(hipMemcpyAsync(host8, h->scalars.p, 8 * sizeof(real), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
@@ -716,7 +717,9 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
     return VS_OK;
 }
 
-int gradient_max(vs_ba *h, real *out)
+// Enqueues max |gradient| at the linearised point (over the shards too) and its copy into
+// host_scalars[8]; the value is there once the stream has been synchronised.
+int gradient_max_enqueue(vs_ba *h)
 {
     const int64_t np = h->fix_points ? 0 : h->Np;
     const int nb = (int)std::min<int64_t>(kGradMaxBlocks, div_up(std::max<int64_t>(6 * (int64_t)h->Nc, np), 256));
@@ -725,8 +728,15 @@ int gradient_max(vs_ba *h, real *out)
     hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(64), 0, h->stream, nb, h->gmax_partial.p, h->scalars.p + 4);
     VS_TRY(launch_check("gradient_max_kernel"));
     VS_TRY(cross_gpu_max(h, h->scalars.p + 4));   // landmark gradients are local to a shard
-    VS_HIP(hipMemcpyAsync(out, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, h->stream));
+    VS_HIP(hipMemcpyAsync(h->host_scalars.p + 8, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, h->stream));
+    return VS_OK;
+}
+
+int gradient_max(vs_ba *h, real *out)
+{
+    VS_TRY(gradient_max_enqueue(h));
     VS_HIP(hipStreamSynchronize(h->stream));
+    *out = h->host_scalars.p[8];
     return VS_OK;
 }
 
@@ -772,6 +782,7 @@ int vs_ba_create(vs_ba_handle *out, int32_t Nc, int32_t Np, int64_t No, double f
     A(h->hub_w.alloc(1)); A(h->scale_c.alloc(6 * (size_t)Nc)); A(h->scale_p.alloc(3 * (size_t)Np));
     A(h->lam_c.alloc(6 * (size_t)Nc)); A(h->dcam.alloc(6 * (size_t)Nc)); A(h->dpt.alloc(3 * (size_t)Np));
     A(h->scalars.alloc(8)); A(h->info.alloc(1)); A(h->linv.alloc(kNB * kNB)); A(h->gmax_partial.alloc(kGradMaxBlocks));
+    A(h->host_scalars.alloc(16));
     if (rc != VS_OK) { delete h; return rc; }
     *out = h;
     return VS_OK;
@@ -1039,22 +1050,36 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
     double cost = 0.0, cost0 = 0.0;
     // initial cost and gradient (unscaled, undamped); the same pass gives the Jacobi scaling
     VS_TRY(unscaled_pass(h));
-    VS_HIP(hipMemcpyAsync(&cost, h->cost(), sizeof(real), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipMemcpyAsync(h->host_scalars.p + 9, h->cost(), sizeof(real), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
-    cost0 = cost;
+    cost0 = cost = h->host_scalars.p[9];
     if (h->No_global == 0) term = 0;
     else {
         real gmax = 0;
         VS_TRY(gradient_max(h, &gmax));
         if (gmax <= o.gradient_tolerance) term = 0;
-        else
+        else {
+            // The gradient test of an accepted point is not waited for: its result arrives with the
+            // scalars of the next step, and a step taken from a point that had already converged is
+            // dropped (one host synchronisation per iteration instead of two).
+            bool gmax_pending = false;
             while (true) {
-                if (it >= o.max_num_iterations) { term = 1; break; }
-                if (radius < o.min_trust_region_radius) { term = 0; break; }
+                if (it >= o.max_num_iterations || radius < o.min_trust_region_radius) {
+                    term = it >= o.max_num_iterations ? 1 : 0;
+                    if (gmax_pending) {
+                        VS_HIP(hipStreamSynchronize(s));
+                        if (h->host_scalars.p[8] <= o.gradient_tolerance) term = 0;
+                    }
+                    break;
+                }
                 it++;
                 StepScalars sc{};
                 bool fail = false;
                 VS_TRY(lm_step_device(h, radius, o.min_lm_diagonal, o.max_lm_diagonal, &sc, &fail, true));
+                if (gmax_pending) {
+                    gmax_pending = false;
+                    if (h->host_scalars.p[8] <= o.gradient_tolerance) { it--; term = 0; break; }
+                }
                 if (fail || !(sc.mcc > 0.0)) {
                     if (++invalid >= o.max_consecutive_invalid_steps) { term = 2; break; }
                     radius *= 0.5;
@@ -1081,13 +1106,14 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
                     VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
                     h->prelin = true;
                     h->prelin_radius = radius;
-                    VS_TRY(gradient_max(h, &gmax));
-                    if (gmax <= o.gradient_tolerance) { term = 0; break; }
+                    VS_TRY(gradient_max_enqueue(h));
+                    gmax_pending = true;
                 } else {
                     radius /= decrease_factor;
                     decrease_factor *= 2.0;
                 }
             }
+        }
     }
     h->linearized = false;
     h->prelin = false;

@@ -71,6 +71,29 @@ struct DevBuf {
     }
 };
 
+// Owning page-locked host buffer: the target of the small device-to-host copies inside a solve (a
+// copy into pageable memory is staged by the runtime and costs several times as much).
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    int alloc(size_t count)
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        hipError_t e = hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return VS_ERR_NOMEM;
+        }
+        return VS_OK;
+    }
+};
+
 // Collective on a vs_comm (comm.hip): in-place sum or max of n doubles at a device pointer, enqueued
 // on stream s (no host synchronisation).
 int comm_allreduce(vs_comm *c, double *buf, int64_t n, bool take_max, hipStream_t s);

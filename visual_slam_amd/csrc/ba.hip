@@ -694,13 +694,16 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
                        h->t2.p, h->rpy2.p, h->pts2.p, h->cand_partial.p);
     VS_TRY(launch_check("candidate_kernel"));
     if (want_candidate_cost) {
-        VS_TRY(prep_cameras(h, h->t2.p, h->rpy2.p));
-        if (h->stage_cams)
+        if (h->stage_cams)   // few cameras: the workgroups build the candidate's camera records themselves
             hipLaunchKernelGGL(cost_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
-                               h->cams.p, h->pts2.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
-        else
+                               (const CamData *)nullptr, h->t2.p, h->rpy2.p, (CamData *)nullptr, h->pts2.p, h->pt_ptr.p,
+                               h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+        else {
+            VS_TRY(prep_cameras(h, h->t2.p, h->rpy2.p));
             hipLaunchKernelGGL(cost_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, Np, Nc, h->K,
-                               h->cams.p, h->pts2.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+                               h->cams.p, (const real *)nullptr, (const real *)nullptr, (CamData *)nullptr, h->pts2.p,
+                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+        }
         VS_TRY(launch_check("cost_kernel"));
     }
     // model cost change, |x|^2, |d|^2, candidate cost and the solver status: one launch, one copy
@@ -724,8 +727,8 @@ int gradient_max_enqueue(vs_ba *h)
     const int64_t np = h->fix_points ? 0 : h->Np;
     const int nb = (int)std::min<int64_t>(kGradMaxBlocks, div_up(std::max<int64_t>(6 * (int64_t)h->Nc, np), 256));
     hipLaunchKernelGGL(gradient_max_kernel, dim3(nb), dim3(256), 0, h->stream, (int64_t)6 * h->Nc, h->gc(), np,
-                       h->lmrec.p, h->gmax_partial.p);
-    hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(64), 0, h->stream, nb, h->gmax_partial.p, h->scalars.p + 4);
+                       h->lmrec.p, nb == 1 ? h->scalars.p + 4 : h->gmax_partial.p);
+    if (nb > 1) hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(64), 0, h->stream, nb, h->gmax_partial.p, h->scalars.p + 4);
     VS_TRY(launch_check("gradient_max_kernel"));
     VS_TRY(cross_gpu_max(h, h->scalars.p + 4));   // landmark gradients are local to a shard
     VS_HIP(hipMemcpyAsync(h->host_scalars.p + 8, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, h->stream));
@@ -874,10 +877,12 @@ int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double
         const size_t lds = cam_lds_bytes(h);
         if (h->stage_cams)
             hipLaunchKernelGGL(cost_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, h->Np, h->Nc, h->K,
-                               h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+                               h->cams.p, (const real *)nullptr, (const real *)nullptr, (CamData *)nullptr, h->pts.p,
+                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
         else
             hipLaunchKernelGGL(cost_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, h->Np, h->Nc, h->K,
-                               h->cams.p, h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+                               h->cams.p, (const real *)nullptr, (const real *)nullptr, (CamData *)nullptr, h->pts.p,
+                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
         VS_TRY(launch_check("cost_kernel"));
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->cost_partial.p, h->scalars.p + 5);
         VS_HIP(hipMemcpyAsync(cost, h->scalars.p + 5, sizeof(real), hipMemcpyDefault, s));

@@ -369,6 +369,33 @@ __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int
     return cost;
 }
 
+// Every camera record into the workgroup's LDS array `scams` (all threads call it; it ends with a
+// barrier).  With prep_t / prep_rpy the records are built from the camera parameters (the array
+// is followed by 6 Nc reals for the sines and cosines: one sincos per thread, 3 Nc of them, instead
+// of three per camera in a single wave) and workgroup 0 also stores them to cams_out; otherwise
+// they are copied from `cams`.
+__device__ __forceinline__ void stage_all_cameras(CamData *scams, int Nc, const CamData *__restrict__ cams,
+                                                  const real *__restrict__ prep_t, const real *__restrict__ prep_rpy,
+                                                  CamData *__restrict__ cams_out)
+{
+    if (prep_t) {
+        real *sc = reinterpret_cast<real *>(scams + Nc);
+        for (int i = threadIdx.x; i < 3 * Nc; i += blockDim.x) sincos(prep_rpy[i], &sc[2 * i], &sc[2 * i + 1]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
+            const real *q = sc + 6 * c;
+            const CamData d = cam_from_sincos(prep_t, c, q[0], q[1], q[2], q[3], q[4], q[5]);
+            scams[c] = d;
+            if (blockIdx.x == 0 && cams_out) cams_out[c] = d;
+        }
+    } else {
+        const double2 *src = reinterpret_cast<const double2 *>(cams);
+        double2 *dst = reinterpret_cast<double2 *>(scams);
+        for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+}
+
 // (a)+(b), landmark side.  kLpl lanes per landmark j share its observations:
 // V_j = sum Jp^T Jp, g_p_j = sum Jp^T r, cost; then Vinv_j = (V_j + damping)^-1.
 // Cameras come from LDS when they all fit (STAGE 1), or when the cameras seen by the landmarks of
@@ -400,25 +427,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
         b = pt_ptr[j]; e = pt_ptr[j + 1];
         P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
     }
-    if (STAGE == 1) {
-        if (prep_t) {
-            // one sincos per thread (3 Nc of them) instead of three per camera in a single wave
-            real *sc = reinterpret_cast<real *>(scams + Nc);
-            for (int i = threadIdx.x; i < 3 * Nc; i += blockDim.x) sincos(prep_rpy[i], &sc[2 * i], &sc[2 * i + 1]);
-            __syncthreads();
-            for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
-                const real *q = sc + 6 * c;
-                const CamData d = cam_from_sincos(prep_t, c, q[0], q[1], q[2], q[3], q[4], q[5]);
-                scams[c] = d;
-                if (blockIdx.x == 0) cams_out[c] = d;
-            }
-        } else {
-            const double2 *src = reinterpret_cast<const double2 *>(cams);
-            double2 *dst = reinterpret_cast<double2 *>(scams);
-            for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
-        }
-        __syncthreads();
-    }
+    if (STAGE == 1) stage_all_cameras(scams, Nc, cams, prep_t, prep_rpy, cams_out);
     int lo = 0;
     if (STAGE == 2) {
         lo = cam_lo[blockIdx.x];
@@ -528,22 +537,19 @@ landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict_
     }
 }
 
-// Cost only (candidate evaluation inside LM): one thread per landmark.
+// Cost only (candidate evaluation inside LM): one thread per landmark.  With STAGE_CAMS and prep_t /
+// prep_rpy given, the workgroups build the camera records themselves (as landmark_kernel<1> does).
 template <bool STAGE_CAMS>
 __global__ void __launch_bounds__(kLmThreads)
-cost_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, const real *__restrict__ pts,
+cost_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, const real *__restrict__ prep_t,
+            const real *__restrict__ prep_rpy, CamData *__restrict__ cams_out, const real *__restrict__ pts,
             const int *__restrict__ pt_ptr, const int *__restrict__ lcam,
             const real *__restrict__ luv, HuberObs hub, real *__restrict__ cost_partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     CamData *scams = reinterpret_cast<CamData *>(smem_raw);
     __shared__ real red[4];
-    if (STAGE_CAMS) {
-        const double2 *src = reinterpret_cast<const double2 *>(cams);
-        double2 *dst = reinterpret_cast<double2 *>(scams);
-        for (int i = threadIdx.x; i < Nc * 8; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-    }
+    if (STAGE_CAMS) stage_all_cameras(scams, Nc, cams, prep_t, prep_rpy, cams_out);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     real cost = real(0);
     if (j < Np) {

@@ -199,6 +199,18 @@ int vs_matcher_set_stream(vs_matcher_handle m, void *hip_stream);
  * x0 < x1 keep distance 1.0 and still compete, superpoint_frontend.cc:117,126-129). */
 int vs_matcher_set_pair(vs_matcher_handle m, int32_t pair, const float *desc0, int32_t n0,
                         const float *desc1, int32_t n1, const int32_t *xy0, const int32_t *xy1);
+/* Loads pairs [first_pair, first_pair + n_pairs) with one call: every pair is n0 x n1, pair p's
+ * descriptors start at desc0 + p * stride0 and desc1 + p * stride1 (strides in floats, at least
+ * n * 256), its keypoints (if given) at xy0 + p * 2 * n0 and xy1 + p * 2 * n1.  The batched form of
+ * the call above (the reference matches one cv::Mat pair per call, superpoint_frontend.cc:163-170);
+ * it is what a caller uses whose descriptors come out of the network as one (pairs, n, 256) array.
+ * Host or device pointers in both calls.  With DEVICE pointers the descriptors are read by a kernel
+ * enqueued on the matcher's stream and the call returns without waiting for it: the arrays must
+ * stay untouched until work enqueued later on that stream has started (or the stream has been
+ * synchronised).  With host pointers the call returns when the caller's arrays are free again. */
+int vs_matcher_set_pairs(vs_matcher_handle m, int32_t first_pair, int32_t n_pairs, const float *desc0,
+                         int64_t stride0, int32_t n0, const float *desc1, int64_t stride1, int32_t n1,
+                         const int32_t *xy0, const int32_t *xy1);
 /* Matches pairs [0, n_pairs) on the device.  Results stay on the device. */
 int vs_matcher_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float ratio);
 /* Copies out pair `pair`'s matches (each array sized >= n0 of that pair). */

@@ -188,3 +188,54 @@ def test_ratio_test_with_stereo_mask_ties_and_tiny_sets(orc):
     same(vm.two_way(e0, e1, 2.0, 0.8), orc.two_way_matching(e0, e1, 2.0, 0.8))
     f0, f1 = synth.make_descriptors(130, 2, seed=3)
     same(vm.two_way(f0, f1, 2.0, 0.8), orc.two_way_matching(f0, f1, 2.0, 0.8))
+
+
+def test_set_pairs_batched_load_equals_per_pair_loads(orc):
+    """vs_matcher_set_pairs (one call, strided pairs; host arrays, device arrays read in place, and
+    device arrays with padded pair strides) gives what per-pair vs_matcher_set_pair gives."""
+    import torch
+    pairs, n0, n1 = 5, 300, 260
+    data = [synth.make_descriptors(n0, n1, seed=70 + p, duplicates=2) for p in range(pairs)]
+    d0 = np.stack([d[0] for d in data]); d1 = np.stack([d[1] for d in data])
+    ref = vm.Matcher(pairs, n0, n1)
+    for p in range(pairs):
+        ref.set_pair(p, d0[p], d1[p])
+    ref.run(pairs, 0.7)
+    want = [ref.matches(p) for p in range(pairs)]
+    same(want[0], orc.two_way_matching(d0[0], d1[0], 0.7))
+    # host arrays
+    mt = vm.Matcher(pairs, n0, n1)
+    mt.set_pairs(0, d0, d1)
+    mt.run(pairs, 0.7)
+    for p in range(pairs):
+        same(mt.matches(p), want[p])
+    # device arrays, read in place (no wait inside the call), pairs 1.. first then pair 0 alone
+    t0 = torch.from_numpy(d0).cuda(); t1 = torch.from_numpy(d1).cuda()
+    mt2 = vm.Matcher(pairs, n0, n1)
+    mt2.set_pairs(1, (t0[1:].data_ptr(), pairs - 1, n0, n0 * 256), (t1[1:].data_ptr(), pairs - 1, n1, n1 * 256))
+    mt2.set_pair(0, (t0.data_ptr(), n0), (t1.data_ptr(), n1))
+    mt2.run(pairs, 0.7)
+    for p in range(pairs):
+        same(mt2.matches(p), want[p])
+    # padded pair stride, and a base address that is not 16-byte aligned (takes the copy path)
+    pad0 = torch.zeros(pairs, n0 + 7, 256, device="cuda"); pad0[:, :n0] = t0
+    flat = torch.zeros(pairs * n1 * 256 + 1, device="cuda"); flat[1:] = t1.reshape(-1)
+    mt3 = vm.Matcher(pairs, n0, n1)
+    mt3.set_pairs(0, (pad0.data_ptr(), pairs, n0, (n0 + 7) * 256), (flat[1:].data_ptr(), pairs, n1, n1 * 256))
+    mt3.run(pairs, 0.7)
+    for p in range(pairs):
+        same(mt3.matches(p), want[p])
+
+
+def test_set_pairs_with_stereo_masks(orc):
+    pairs, n0, n1 = 3, 200, 180
+    rng = np.random.default_rng(5)
+    data = [synth.make_descriptors(n0, n1, seed=90 + p) for p in range(pairs)]
+    d0 = np.stack([d[0] for d in data]); d1 = np.stack([d[1] for d in data])
+    xy0 = rng.integers(0, 200, size=(pairs, n0, 2)).astype(np.int32)
+    xy1 = rng.integers(0, 200, size=(pairs, n1, 2)).astype(np.int32)
+    mt = vm.Matcher(pairs, n0, n1)
+    mt.set_pairs(0, d0, d1, xy0, xy1)
+    mt.run(pairs, 0.7)
+    for p in range(pairs):
+        same(mt.matches(p), orc.stereo_matching(d0[p], xy0[p], d1[p], xy1[p], 0.7))

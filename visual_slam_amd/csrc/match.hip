@@ -57,6 +57,10 @@ constexpr float kAccumRel = 256.0f * 1.1920929e-7f + 7.6293945e-6f;
 constexpr float kNegInf = -3.0e38f;
 constexpr float kMaskedDot = 0.5f * kDotScale;   // distance 1.0  <=>  dot 0.5
 
+struct PairDims {
+    int n0, n1;
+};
+
 constexpr int kSplitRows = 32;          // rows per workgroup of split_kernel
 
 // fp32 rows -> fp16 rows scaled by 2^8 (n_pad rows, rows >= n zero-filled).  One wave per row,
@@ -104,6 +108,83 @@ split_kernel(const float *__restrict__ src, int n, int n_pad, _Float16 *__restri
     }
 }
 
+// The same rounding for a run of frame pairs in one launch (vs_matcher_set_pair / set_pairs):
+// grid = (row blocks, side, pair).  Side 0 reads pair p's rows at src0 + p * stride0 (floats), side 1
+// at src1 + p * stride1; the rows are also copied into the handle's own fp32 arrays (copy0 / copy1,
+// pair pitch n_pad * 256) unless they already are those arrays.  Instead of atomics on the
+// statistics every workgroup stores its two maxima to `part` ([pair][side][block][2]);
+// split_finish_kernel reduces them, so nothing has to be zeroed first.
+__global__ void __launch_bounds__(256)
+split_pairs_kernel(const float *__restrict__ src0, int64_t stride0, int n0, int n0_pad,
+                   const float *__restrict__ src1, int64_t stride1, int n1, int n1_pad,
+                   float *__restrict__ copy0, float *__restrict__ copy1, _Float16 *__restrict__ a16,
+                   _Float16 *__restrict__ b16, int first_pair, int part_blocks, float *__restrict__ part)
+{
+    __shared__ float wmax[2][4];
+    const int side = blockIdx.y, p = blockIdx.z, pair = first_pair + p;
+    const int n = side ? n1 : n0, n_pad = side ? n1_pad : n0_pad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float res_max = 0.f, nrm_max = 0.f;
+    if ((int)blockIdx.x * kSplitRows < n_pad) {
+        const float *src = side ? src1 + (int64_t)p * stride1 : src0 + (int64_t)p * stride0;
+        float *copy = (side ? copy1 : copy0) + (int64_t)pair * n_pad * kD;
+        _Float16 *hi = (side ? b16 : a16) + (int64_t)pair * n_pad * kD;
+        for (int q = 0; q < kSplitRows / 4; q++) {
+            const int row = blockIdx.x * kSplitRows + q * 4 + wave;
+            if (row >= n_pad) break;
+            const int64_t e = (int64_t)row * kD + lane * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < n) {
+                v = *reinterpret_cast<const float4 *>(src + e);
+                if (src != copy) *reinterpret_cast<float4 *>(copy + e) = v;
+            }
+            const float x[4] = { v.x * kScale, v.y * kScale, v.z * kScale, v.w * kScale };
+            _Float16 h[4];
+            float res2 = 0.f, nrm2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                h[k] = (_Float16)x[k];
+                const float hf = (float)h[k], r = x[k] - hf;    // the residue is exact in fp32
+                res2 = fmaf(r, r, res2);
+                nrm2 = fmaf(hf, hf, nrm2);
+            }
+            *reinterpret_cast<uint2 *>(hi + e) = *reinterpret_cast<uint2 *>(h);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                res2 += __shfl_xor(res2, off, 64);
+                nrm2 += __shfl_xor(nrm2, off, 64);
+            }
+            res_max = fmaxf(res_max, res2);
+            nrm_max = fmaxf(nrm_max, nrm2);
+        }
+    }
+    if (lane == 0) { wmax[0][wave] = res_max; wmax[1][wave] = nrm_max; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        part[(((int64_t)p * 2 + side) * part_blocks + blockIdx.x) * 2 + threadIdx.x] =
+            fmaxf(fmaxf(wmax[threadIdx.x][0], wmax[threadIdx.x][1]), fmaxf(wmax[threadIdx.x][2], wmax[threadIdx.x][3]));
+}
+
+// One wave per pair: the maxima over the workgroups of split_pairs_kernel become the pair's four
+// statistics, and the pair's sizes are written.
+__global__ void __launch_bounds__(64)
+split_finish_kernel(int first_pair, int part_blocks, const float *__restrict__ part, int n0, int n1,
+                    unsigned *__restrict__ stats, PairDims *__restrict__ dims)
+{
+    const int p = blockIdx.x, pair = first_pair + p, lane = threadIdx.x;
+    float m[4] = { 0.f, 0.f, 0.f, 0.f };   // side 0 residue, side 0 norm, side 1 residue, side 1 norm
+    for (int b = lane; b < part_blocks; b += 64)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            m[k] = fmaxf(m[k], part[(((int64_t)p * 2 + (k >> 1)) * part_blocks + b) * 2 + (k & 1)]);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], off, 64));
+    if (lane < 4) stats[4 * (int64_t)pair + lane] = __float_as_uint(lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3]);
+    if (lane == 0) { dims[pair].n0 = n0; dims[pair].n1 = n1; }
+}
+
 // Certainty band of one frame pair in units of s~ (= 2^16 * dot): twice the bound on |s~ - s|
 // plus the collapse margin.  stats = { max||a-a16||^2, max||a16||^2, max||b-b16||^2, max||b16||^2 }.
 __device__ __forceinline__ float pair_band(const unsigned *__restrict__ stats, int pair)
@@ -147,10 +228,6 @@ __device__ __forceinline__ void top2_union(float &b1, float &b2, float ob1, floa
     b1 = fmaxf(b1, ob1);
     b2 = fmaxf(lo, fmaxf(b2, ob2));
 }
-
-struct PairDims {
-    int n0, n1;
-};
 
 // LDS image of one streamed desc1 K-step: kBN rows (columns of the score tile) x kBK halfs in
 // unpadded rows whose 16-byte chunks are XOR-swizzled with the row number so that the
@@ -937,6 +1014,8 @@ struct vs_matcher {
     DevBuf<float> d0, d1;
     DevBuf<_Float16> a16, b16;
     DevBuf<unsigned> stats;          // 4 per pair, see pair_band()
+    DevBuf<float> split_part;        // per-workgroup maxima of split_pairs_kernel
+    int part_blocks = 0;
     DevBuf<int2> xy0, xy1;
     DevBuf<PairDims> dims;
     DevBuf<float2> row_part, col_part;   // (best, second) packed scores per item and 64-chunk
@@ -971,6 +1050,8 @@ int vs_matcher_create(vs_matcher_handle *out, int32_t max_pairs, int32_t max_n0,
     A(m->d0.alloc(P * r0 * kD)); A(m->d1.alloc(P * r1 * kD));
     A(m->a16.alloc(P * r0 * kD)); A(m->b16.alloc(P * r1 * kD)); A(m->stats.alloc(4 * P));
     A(m->xy0.alloc(P * r0)); A(m->xy1.alloc(P * r1)); A(m->dims.alloc(P));
+    m->part_blocks = div_up(std::max(m->n0_pad, m->n1_pad), kSplitRows);
+    A(m->split_part.alloc(P * 2 * (size_t)m->part_blocks * 2));
     const size_t rp = P * (r1 / kSub) * r0, cp = P * (r0 / kSub) * r1;
     A(m->row_part.alloc(rp)); A(m->col_part.alloc(cp));
     A(m->idx0.alloc(P * r0)); A(m->idx1.alloc(P * r1)); A(m->dist0.alloc(P * r0)); A(m->dist1.alloc(P * r1));
@@ -997,6 +1078,64 @@ int vs_matcher_set_stream(vs_matcher_handle m, void *stream)
     return VS_OK;
 }
 
+// Is `p` device memory (hipMalloc'd, or any pointer the device can read in place)?
+static bool device_readable(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice;
+}
+
+// Descriptors (and keypoints) of pairs [first, first + n_pairs), every pair n0 x n1; pair p's rows
+// at desc + p * stride floats (keypoints dense: 2 n ints per pair).  Device inputs are read in
+// place by the rounding kernel, which also copies them into the handle, and the call returns
+// without waiting for the stream; host inputs are copied first and the call waits, so that the
+// caller's buffers are free on return.
+static int set_pairs_impl(vs_matcher *m, int first, int n_pairs, const float *desc0, int64_t stride0, int n0,
+                          const float *desc1, int64_t stride1, int n1, const int32_t *xy0, const int32_t *xy1)
+{
+    hipStream_t s = m->stream;
+    const size_t e0 = (size_t)m->n0_pad * kD, e1 = (size_t)m->n1_pad * kD;
+    float *g0 = m->d0.p + (size_t)first * e0, *g1 = m->d1.p + (size_t)first * e1;
+    bool host_input = false;
+    // read in place: device memory the kernel can fetch as aligned 16-byte pieces
+    auto in_place = [&](const float *d, int64_t stride, int n) {
+        if (n == 0) return true;
+        const bool dev = device_readable(d);
+        host_input = host_input || !dev;
+        return dev && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && stride % 4 == 0;
+    };
+    const bool dev0 = in_place(desc0, stride0, n0), dev1 = in_place(desc1, stride1, n1);
+    if (!dev0)
+        VS_HIP(hipMemcpy2DAsync(g0, e0 * sizeof(float), desc0, (size_t)stride0 * sizeof(float), (size_t)n0 * kD * sizeof(float),
+                                (size_t)n_pairs, hipMemcpyDefault, s));
+    if (!dev1)
+        VS_HIP(hipMemcpy2DAsync(g1, e1 * sizeof(float), desc1, (size_t)stride1 * sizeof(float), (size_t)n1 * kD * sizeof(float),
+                                (size_t)n_pairs, hipMemcpyDefault, s));
+    if (xy0) {
+        host_input = host_input || (n0 && !device_readable(xy0)) || (n1 && !device_readable(xy1));
+        if (n0) VS_HIP(hipMemcpy2DAsync(m->xy0.p + (size_t)first * m->n0_pad, (size_t)m->n0_pad * sizeof(int2), xy0, (size_t)n0 * sizeof(int2),
+                                        (size_t)n0 * sizeof(int2), (size_t)n_pairs, hipMemcpyDefault, s));
+        if (n1) VS_HIP(hipMemcpy2DAsync(m->xy1.p + (size_t)first * m->n1_pad, (size_t)m->n1_pad * sizeof(int2), xy1, (size_t)n1 * sizeof(int2),
+                                        (size_t)n1 * sizeof(int2), (size_t)n_pairs, hipMemcpyDefault, s));
+    }
+    // sources of the rounding kernel: the caller's device arrays, or the copies just made
+    const float *s0 = dev0 && n0 ? desc0 : g0, *s1 = dev1 && n1 ? desc1 : g1;
+    const int64_t st0 = dev0 && n0 ? stride0 : (int64_t)e0, st1 = dev1 && n1 ? stride1 : (int64_t)e1;
+    float *part = m->split_part.p + (size_t)first * 2 * m->part_blocks * 2;
+    hipLaunchKernelGGL(split_pairs_kernel, dim3(m->part_blocks, 2, n_pairs), dim3(256), 0, s, s0, st0, n0, m->n0_pad, s1, st1, n1,
+                       m->n1_pad, m->d0.p, m->d1.p, m->a16.p, m->b16.p, first, m->part_blocks, part);
+    hipLaunchKernelGGL(split_finish_kernel, dim3(n_pairs), dim3(64), 0, s, first, m->part_blocks, part, n0, n1, m->stats.p, m->dims.p);
+    VS_TRY(launch_ok("split_pairs_kernel"));
+    for (int p = first; p < first + n_pairs; p++) {
+        m->h_dims[p] = PairDims{ n0, n1 };
+        m->h_masked[p] = xy0 != nullptr;
+    }
+    if (host_input) VS_HIP(hipStreamSynchronize(s));
+    m->ran = false;
+    return VS_OK;
+}
+
 int vs_matcher_set_pair(vs_matcher_handle m, int32_t pair, const float *desc0, int32_t n0,
                         const float *desc1, int32_t n1, const int32_t *xy0, const int32_t *xy1)
 {
@@ -1006,27 +1145,23 @@ int vs_matcher_set_pair(vs_matcher_handle m, int32_t pair, const float *desc0, i
              "pair sizes %d x %d exceed the matcher's capacity %d x %d", n0, n1, m->n0_pad, m->n1_pad);
     VS_CHECK((n0 == 0 || desc0) && (n1 == 0 || desc1), VS_ERR_INVALID, "null descriptor pointer");
     VS_CHECK((xy0 == nullptr) == (xy1 == nullptr), VS_ERR_INVALID, "xy0 and xy1 must both be given or both be NULL");
-    hipStream_t s = m->stream;
-    float *g0 = m->d0.p + (size_t)pair * m->n0_pad * kD, *g1 = m->d1.p + (size_t)pair * m->n1_pad * kD;
-    if (n0) VS_HIP(hipMemcpyAsync(g0, desc0, (size_t)n0 * kD * sizeof(float), hipMemcpyDefault, s));
-    if (n1) VS_HIP(hipMemcpyAsync(g1, desc1, (size_t)n1 * kD * sizeof(float), hipMemcpyDefault, s));
-    if (xy0) {
-        if (n0) VS_HIP(hipMemcpyAsync(m->xy0.p + (size_t)pair * m->n0_pad, xy0, (size_t)n0 * sizeof(int2), hipMemcpyDefault, s));
-        if (n1) VS_HIP(hipMemcpyAsync(m->xy1.p + (size_t)pair * m->n1_pad, xy1, (size_t)n1 * sizeof(int2), hipMemcpyDefault, s));
-    }
-    const size_t e0 = (size_t)m->n0_pad * kD, e1 = (size_t)m->n1_pad * kD;
-    VS_HIP(hipMemsetAsync(m->stats.p + 4 * (size_t)pair, 0, 4 * sizeof(unsigned), s));
-    hipLaunchKernelGGL(split_kernel, dim3(div_up(m->n0_pad, kSplitRows)), dim3(256), 0, s, g0, n0, m->n0_pad,
-                       m->a16.p + (size_t)pair * e0, m->stats.p + 4 * (size_t)pair);
-    hipLaunchKernelGGL(split_kernel, dim3(div_up(m->n1_pad, kSplitRows)), dim3(256), 0, s, g1, n1, m->n1_pad,
-                       m->b16.p + (size_t)pair * e1, m->stats.p + 4 * (size_t)pair + 2);
-    VS_TRY(launch_ok("split_kernel"));
-    m->h_dims[pair] = PairDims{ n0, n1 };
-    m->h_masked[pair] = xy0 != nullptr;
-    VS_HIP(hipMemcpyAsync(m->dims.p + pair, &m->h_dims[pair], sizeof(PairDims), hipMemcpyHostToDevice, s));
-    VS_HIP(hipStreamSynchronize(s));
-    m->ran = false;
-    return VS_OK;
+    return set_pairs_impl(m, pair, 1, desc0, (int64_t)n0 * kD, n0, desc1, (int64_t)n1 * kD, n1, xy0, xy1);
+}
+
+int vs_matcher_set_pairs(vs_matcher_handle m, int32_t first_pair, int32_t n_pairs, const float *desc0,
+                         int64_t stride0, int32_t n0, const float *desc1, int64_t stride1, int32_t n1,
+                         const int32_t *xy0, const int32_t *xy1)
+{
+    VS_CHECK(m != nullptr, VS_ERR_INVALID, "null handle");
+    VS_CHECK(n_pairs > 0 && first_pair >= 0 && first_pair <= m->max_pairs - n_pairs, VS_ERR_INVALID,
+             "pairs [%d, %d) out of range [0,%d)", first_pair, first_pair + n_pairs, m->max_pairs);
+    VS_CHECK(n0 >= 0 && n0 <= m->n0_pad && n1 >= 0 && n1 <= m->n1_pad, VS_ERR_INVALID,
+             "pair sizes %d x %d exceed the matcher's capacity %d x %d", n0, n1, m->n0_pad, m->n1_pad);
+    VS_CHECK((n0 == 0 || desc0) && (n1 == 0 || desc1), VS_ERR_INVALID, "null descriptor pointer");
+    VS_CHECK(stride0 >= (int64_t)n0 * kD && stride1 >= (int64_t)n1 * kD, VS_ERR_INVALID,
+             "pair strides %lld / %lld must cover %d / %d rows of 256 floats", (long long)stride0, (long long)stride1, n0, n1);
+    VS_CHECK((xy0 == nullptr) == (xy1 == nullptr), VS_ERR_INVALID, "xy0 and xy1 must both be given or both be NULL");
+    return set_pairs_impl(m, first_pair, n_pairs, desc0, stride0, n0, desc1, stride1, n1, xy0, xy1);
 }
 
 // Device buffers one matcher run works on (all pairs of a batch share the row pads).

@@ -58,6 +58,26 @@ class Matcher:
                                            ptr(x1, C.c_int32)))
         self.sizes[int(pair)] = (n0, n1)
 
+    def set_pairs(self, first_pair, desc0, desc1, xy0=None, xy1=None):
+        """vs_matcher_set_pairs: desc0/desc1 are (pairs, n, 256) float32 numpy arrays, or
+        (device_address, pairs, n, stride_in_floats) tuples; xy0/xy1 (pairs, n, 2) int32 or None."""
+        def unpack(d):
+            if isinstance(d, tuple):
+                return int(d[0]), int(d[1]), int(d[2]), int(d[3])
+            d = _f32(d)
+            assert d.ndim == 3 and d.shape[2] == DESC_DIM
+            return d, d.shape[0], d.shape[1], d.shape[1] * DESC_DIM
+        d0, p0, n0, s0 = unpack(desc0)
+        d1, p1, n1, s1 = unpack(desc1)
+        assert p0 == p1
+        x0 = None if xy0 is None else _i32(xy0).reshape(p0, n0, 2)
+        x1 = None if xy1 is None else _i32(xy1).reshape(p0, n1, 2)
+        check(self.lib.vs_matcher_set_pairs(self.h, int(first_pair), p0, ptr(d0, C.c_float), C.c_int64(s0), n0,
+                                            ptr(d1, C.c_float), C.c_int64(s1), n1, ptr(x0, C.c_int32),
+                                            ptr(x1, C.c_int32)))
+        for p in range(p0):
+            self.sizes[int(first_pair) + p] = (n0, n1)
+
     def run(self, n_pairs, nn_thresh=2.0, ratio=1.0):
         check(self.lib.vs_matcher_run(self.h, int(n_pairs), C.c_float(nn_thresh), C.c_float(ratio)))
 

@@ -1,6 +1,7 @@
 // Host side of the bundle-adjustment C ABI: index-structure construction, kernel sequencing,
 // the Levenberg-Marquardt loop.  Reference interfaces replaced are cited in include/vslam_hip.h.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -179,6 +180,15 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
 {
     const int Nc = h->Nc, Np = h->Np;
     const int64_t Ng = h->No_global;
+    // VS_BA_BUILD_TIMING=1 prints where the time of this function goes (developer knob)
+    const bool timing = getenv("VS_BA_BUILD_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "build_structure: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     for (int64_t o = 0; o < Ng; o++) {
         VS_CHECK(cam[o] >= 0 && cam[o] < Nc, VS_ERR_INVALID, "observation %lld: camera index %d out of range [0,%d)", (long long)o, cam[o], Nc);
         VS_CHECK(pt[o] >= 0 && pt[o] < Np, VS_ERR_INVALID, "observation %lld: point index %d out of range [0,%d)", (long long)o, pt[o], Np);
@@ -192,6 +202,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         std::vector<int64_t> fill(gptr.begin(), gptr.end() - 1);
         for (int64_t o = 0; o < Ng; o++) gord[fill[pt[o]]++] = o;
     }
+    lap("landmark CSR");
     // shard: contiguous landmark range balanced by observation count
     int pt_lo = 0, pt_hi = Np;
     if (h->world > 1) {
@@ -216,10 +227,27 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     for (int64_t o = 0; o < Ng; o++) { cam_used[cam[o]] = 1; pt_used[pt[o]] = 1; }
     h->hub = HuberObs{ -1, -1, -1, (real)h->huber_a };
     std::vector<std::pair<int, int64_t>> tmp;
-    // global pattern of camera pairs + local entries
+    // Global pattern of camera pairs + local entries.  Every pair met gets a slot number in order
+    // of discovery (a dense Nc x Nc table when that is small, else a hash map); the slots of the
+    // local landmarks' pairs are kept in the order they are met, so the two passes that bin the
+    // entries by block below are linear walks with no lookups.
+    const bool dense_pairs = (int64_t)Nc * Nc <= ((int64_t)1 << 24);
+    std::vector<int32_t> pair_tab;
     PairMap pmap;
-    pmap.init(1 << 16);
+    if (dense_pairs) pair_tab.assign((size_t)Nc * Nc, -1); else pmap.init(1 << 16);
     std::vector<uint64_t> uniq;
+    std::vector<int32_t> pair_slot;
+    pair_slot.reserve((size_t)std::max<int64_t>(Ng, 16) * 2);
+    auto slot_of = [&](int a, int c) -> int32_t {
+        const uint64_t key = ((uint64_t)(uint32_t)a << 32) | (uint32_t)c;
+        if (dense_pairs) {
+            int32_t &t = pair_tab[(size_t)a * Nc + c];
+            if (t < 0) { t = (int32_t)uniq.size(); uniq.push_back(key); }
+            return t;
+        }
+        if (pmap.insert(key)) { pmap.set(key, (int32_t)uniq.size()); uniq.push_back(key); }
+        return pmap.get(key);
+    };
     for (int j = 0; j < Np; j++) {
         const int64_t b = gptr[j], e = gptr[j + 1];
         tmp.clear();
@@ -240,35 +268,35 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         } else {
             pt_ptr[j] = j < pt_lo ? 0 : No;
         }
-        {
-            for (size_t a = 0; a < tmp.size(); a++)
-                for (size_t c = a + 1; c < tmp.size(); c++) {
-                    const uint64_t key = ((uint64_t)(uint32_t)tmp[a].first << 32) | (uint32_t)tmp[c].first;
-                    if (pmap.insert(key)) uniq.push_back(key);
-                }
-        }
+        for (size_t a = 0; a < tmp.size(); a++)
+            for (size_t c = a + 1; c < tmp.size(); c++) {
+                const int32_t sl = slot_of(tmp[a].first, tmp[c].first);
+                if (local) pair_slot.push_back(sl);
+            }
     }
+    lap("landmark-major + pair pattern");
     pt_ptr[Np] = No;
     for (int j = pt_hi; j < Np; j++) pt_ptr[j] = No;
     VS_CHECK(Ng < ((int64_t)1 << 31), VS_ERR_UNSUPPORTED, "more than 2^31 observations");
-    std::sort(uniq.begin(), uniq.end());
+    // blocks in (row, column) order: block number of every discovery slot
     const int nb_off = (int)uniq.size();
+    std::vector<int32_t> slot_block((size_t)nb_off);
+    {
+        std::vector<std::pair<uint64_t, int32_t>> keyed((size_t)nb_off);
+        for (int b = 0; b < nb_off; b++) keyed[b] = { uniq[b], b };
+        std::sort(keyed.begin(), keyed.end());
+        for (int b = 0; b < nb_off; b++) { uniq[b] = keyed[b].first; slot_block[keyed[b].second] = b; }
+    }
     h->nb_off = nb_off;
     h->h_brow.resize((size_t)nb_off); h->h_bcol.resize((size_t)nb_off);
     h->max_pair_gap = 0;
     for (int b = 0; b < nb_off; b++) {
-        pmap.set(uniq[b], b);
         h->h_brow[b] = (int32_t)(uniq[b] >> 32); h->h_bcol[b] = (int32_t)(uniq[b] & 0xffffffffu);
         h->max_pair_gap = std::max(h->max_pair_gap, h->h_bcol[b] - h->h_brow[b]);
     }
     // local entries per block (counting sort; landmarks ascending within a block)
     std::vector<int> bptr((size_t)nb_off + 1, 0);
-    for (int j = pt_lo; j < pt_hi; j++) {
-        const int b = pt_ptr[j], e = (j + 1 < Np) ? pt_ptr[j + 1] : No;
-        for (int a = b; a < e; a++)
-            for (int c = a + 1; c < e; c++)
-                bptr[pmap.get(((uint64_t)(uint32_t)lcam[a] << 32) | (uint32_t)lcam[c]) + 1]++;
-    }
+    for (int32_t &sl : pair_slot) { sl = slot_block[sl]; bptr[sl + 1]++; }
     for (int b = 0; b < nb_off; b++) {
         VS_CHECK((int64_t)bptr[b + 1] + bptr[b] < ((int64_t)1 << 31), VS_ERR_UNSUPPORTED, "more than 2^31 camera-pair entries on one GPU");
         bptr[b + 1] += bptr[b];
@@ -277,13 +305,13 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     std::vector<int> bent((size_t)std::max(n_ent, 1));
     {
         std::vector<int> fill(bptr.begin(), bptr.end() - 1);
+        size_t at = 0;                                     // pair_slot follows the landmarks in order
         for (int j = pt_lo; j < pt_hi; j++) {
-            const int b = pt_ptr[j], e = (j + 1 < Np) ? pt_ptr[j + 1] : No;
-            for (int a = b; a < e; a++)
-                for (int c = a + 1; c < e; c++)
-                    bent[fill[pmap.get(((uint64_t)(uint32_t)lcam[a] << 32) | (uint32_t)lcam[c])]++] = j;
+            const int64_t k = ((j + 1 < Np) ? pt_ptr[j + 1] : No) - pt_ptr[j];
+            for (int64_t q = k * (k - 1) / 2; q > 0; q--) bent[fill[pair_slot[at++]]++] = j;
         }
     }
+    lap("pair entries");
     // camera-major view of the local observations
     std::vector<int> cam_ptr((size_t)Nc + 1, 0), cpt((size_t)std::max(No, 1));
     std::vector<real> cuv((size_t)std::max(No, 1) * 2);
@@ -296,6 +324,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
             cpt[k] = lpt[p]; cuv[2 * (size_t)k] = luv[2 * (size_t)p]; cuv[2 * (size_t)k + 1] = luv[2 * (size_t)p + 1];
         }
     }
+    lap("camera-major view");
     // work items: one workgroup each; 4 waves per item and 4 entries per thread when the typical
     // block is large, else 1 wave and 3 entries (measured optima at 50 / 1000 / 10000 cameras).  Blocks that fit one item are written by the block kernel directly,
     // the others go through partials + finalize.
@@ -422,6 +451,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
         h->lds_cam_grid = std::max(1, std::min(cus, div_up(h->n_lm4_blocks, kLmBigThreads / kLmThreads)));
     }
 
+    lap("work items");
     hipStream_t s = h->stream;
     VS_TRY(h->pt_ptr.upload(pt_ptr.data(), pt_ptr.size(), s));
     VS_TRY(h->lcam.upload(lcam.data(), lcam.size(), s));
@@ -455,6 +485,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     const real one_r = 1.0;
     VS_HIP(hipMemcpyAsync(h->hub_w.p, &one_r, sizeof(real), hipMemcpyHostToDevice, s));
     VS_HIP(hipStreamSynchronize(s));
+    lap("allocations + uploads");
     h->have_obs = true;
     h->linearized = false;
     h->have_scale = false; h->prelin = false;

@@ -228,20 +228,21 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     h->hub = HuberObs{ -1, -1, -1, (real)h->huber_a };
     std::vector<std::pair<int, int64_t>> tmp;
     // Global pattern of camera pairs + local entries.  Every pair met gets a slot number in order
-    // of discovery (a dense Nc x Nc table when that is small, else a hash map); the slots of the
-    // local landmarks' pairs are kept in the order they are met, so the two passes that bin the
-    // entries by block below are linear walks with no lookups.
-    const bool dense_pairs = (int64_t)Nc * Nc <= ((int64_t)1 << 24);
-    std::vector<int32_t> pair_tab;
+    // of discovery: pairs (a, c) with c - a < kNear (keyframes in time order: nearly all of them)
+    // through a table of Nc x kNear slots, the others through a hash map.  The slots of the local
+    // landmarks' pairs are kept in the order they are met, so the two passes that bin the entries
+    // by block below are linear walks with no lookups.
+    constexpr int kNear = 64;
+    std::vector<int32_t> near_tab((size_t)Nc * kNear, -1);
     PairMap pmap;
-    if (dense_pairs) pair_tab.assign((size_t)Nc * Nc, -1); else pmap.init(1 << 16);
+    pmap.init(1 << 12);
     std::vector<uint64_t> uniq;
     std::vector<int32_t> pair_slot;
     pair_slot.reserve((size_t)std::max<int64_t>(Ng, 16) * 2);
     auto slot_of = [&](int a, int c) -> int32_t {
         const uint64_t key = ((uint64_t)(uint32_t)a << 32) | (uint32_t)c;
-        if (dense_pairs) {
-            int32_t &t = pair_tab[(size_t)a * Nc + c];
+        if (c - a < kNear) {
+            int32_t &t = near_tab[(size_t)a * kNear + (c - a)];
             if (t < 0) { t = (int32_t)uniq.size(); uniq.push_back(key); }
             return t;
         }

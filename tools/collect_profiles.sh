@@ -26,6 +26,8 @@ run_trace lm_c2 python3 tools/time_lm.py c2 &&
 run_trace lm_c4 python3 tools/time_lm.py c4 &&
 run_trace lm_c5shard python3 tools/time_lm.py c5shard &&
 run_trace lm_c5 python3 tools/time_lm.py c5 &&
+run_trace solve_c4 python3 tools/time_solve.py c4 &&
+run_trace solve_c1 python3 tools/time_solve.py c1 &&
 run_pmc c2_fetch FETCH_SIZE python3 tools/prof_ba.py c2 5 &&
 run_pmc c2_write WRITE_SIZE python3 tools/prof_ba.py c2 5 &&
 run_pmc c4_fetch FETCH_SIZE python3 tools/prof_ba.py c4 5 &&

@@ -278,7 +278,7 @@ __device__ __forceinline__ void store_records(real *stage, int lane, int jw, int
 // (c_first, uv_first) = camera index and pixel of observation b + sl (unused when b + sl >= e),
 // `fetch(c, cd)` delivers camera c's record.  Returns the landmark's cost in lane 0 of the group,
 // zero elsewhere.
-template <typename CamFetch>
+template <bool EARLY_DAMP, typename CamFetch>
 __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int e, const real *P, const Intr &K,
                                                const int *__restrict__ lcam, const real *__restrict__ luv,
                                                const HuberObs &hub, const PointDamping &damp,
@@ -288,6 +288,15 @@ __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int
     real acc[10];                                      // V (6), g (3), cost
 #pragma unroll
     for (int v = 0; v < 10; v++) acc[v] = real(0);
+    // With EARLY_DAMP the landmark's damping input (explicit values or Jacobi scales) is asked for
+    // before the observation loop, so that its memory latency passes behind the loop instead of
+    // after it (three more live registers: not for the kernel that sits at its register limit).
+    real dmp[3] = { real(0), real(0), real(0) };
+    auto load_damping = [&]() {
+        const real *src = damp.lam_p ? damp.lam_p : damp.scale_p;
+        if (src) { dmp[0] = src[3 * j]; dmp[1] = src[3 * j + 1]; dmp[2] = src[3 * j + 2]; }
+    };
+    if (EARLY_DAMP && j < Np && sl == 0) load_damping();
     if (j < Np) {
         // the next observation's camera index and pixel are fetched while this one is processed
         // (the lane's first observation arrives from the caller, who may have fetched it early)
@@ -336,15 +345,16 @@ __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int
         if (Vdiag) { Vdiag[3 * j] = V[0]; Vdiag[3 * j + 1] = V[3]; Vdiag[3 * j + 2] = V[5]; }
         real vi[6] = { 0, 0, 0, 0, 0, 0 };
         if (e > b) {
+            if (!EARLY_DAMP) load_damping();
             real l0 = 0, l1 = 0, l2 = 0;
             if (damp.lam_p) {
-                l0 = damp.lam_p[3 * j]; l1 = damp.lam_p[3 * j + 1]; l2 = damp.lam_p[3 * j + 2];
+                l0 = dmp[0]; l1 = dmp[1]; l2 = dmp[2];
             } else if (damp.scale_p) {
                 const real d[3] = { V[0], V[3], V[5] };
                 real l[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const real s = damp.scale_p[3 * j + k], s2 = s * s;
+                    const real s = dmp[k], s2 = s * s;
                     real x = s2 * d[k];
                     x = x < damp.min_d ? damp.min_d : x;
                     x = x > damp.max_d ? damp.max_d : x;
@@ -441,7 +451,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
     double2 uv_first = make_double2(0, 0);
     if (b + sl < e) { c_first = lcam[b + sl]; uv_first = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(b + sl)); }
     double2 rec[6] = {};
-    const real cost = landmark_lanes(j, sl, Np, b, e, P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_first, uv_first,
+    const real cost = landmark_lanes<true>(j, sl, Np, b, e, P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_first, uv_first,
                                      [&](int c, CamData &cd) { if (STAGE == 0) load_cam(cams, c, cd); else cd = scams[c - lo]; });
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -516,7 +526,7 @@ landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict_
         load_own(t0 + 2 * stride, nn);
         load_first(nxt, c_nxt, uv_nxt);
         double2 rec[6] = {};
-        real v = landmark_lanes(cur.j, sl, Np, cur.b, cur.e, cur.P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_cur, uv_cur,
+        real v = landmark_lanes<false>(cur.j, sl, Np, cur.b, cur.e, cur.P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_cur, uv_cur,
                                 [&](int c, CamData &cd) {
                                     const double2 *src = scam + 7 * c;
                                     double2 *dst = reinterpret_cast<double2 *>(&cd);

@@ -370,9 +370,16 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         // Wait until this wave's share of stage s has landed; after the barrier every wave's has,
         // and every wave has finished reading ring slot (s - 1) % kRing, which is refilled next.
         // Loads return in issue order, so allowing the DMAs of the kRing - 2 younger stages to
-        // stay in flight retires stage s; the first step of a tile (the epilogue's stores sit
-        // between the DMAs) and the tail of the band (fewer younger stages exist) drain fully.
-        if (kt == 0 || s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stay in flight retires stage s; the first step of a band and the tail of the band (fewer
+        // younger stages exist) drain fully.
+        // The first step of a later tile follows the two partial stores of the tile before it: they
+        // are the youngest vector-memory operations (the counter retires loads and stores in issue
+        // order), so they may stay in flight too -- waiting for them would expose a store latency
+        // per tile.
+        if (kt == 0 && tc > c_begin) {
+            if (s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInflight + 2) : "memory");
+        } else if (kt == 0 || s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInflight) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -479,6 +486,10 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         b2 = vmax(b2, t_);                                                                   \
     } while (0)
     const unsigned half_bit = (unsigned)half << 5;
+    // The column partial leaves together with the row partial at the end of the tile: the compiler
+    // cannot tell the transposition area from the LDS-DMA ring and drains the vector-memory counter
+    // before the transposition reads, which would also wait for a store issued before them.
+    float2 col_out;
     // columns: top-2 over the wave's 64 rows; position code e = 32*half + 16*m + r stands for
     // row m*32 + (r&3) + 8*(r>>2) + 4*half of the wave's 64 (decoded by col_position())
     {
@@ -500,8 +511,7 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c2[0]), __float_as_uint(c2[1]), false, false);
         float b1 = __uint_as_float(s1[0]), b2 = __uint_as_float(s2[0]);
         top2_union(b1, b2, __uint_as_float(s1[1]), __uint_as_float(s2[1]));
-        const int64_t o = ((int64_t)pair * (n0_pad / kSub) + (i0 / kSub + wr)) * n1_pad + j0 + wc * 64 + half * 32 + l31;
-        col_part[o] = make_float2(b1, b2);
+        col_out = make_float2(b1, b2);
     }
     __builtin_amdgcn_sched_barrier(0);
     VS_STAMP();
@@ -535,6 +545,8 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         top2_union(b1, b2, __uint_as_float(s1[1]), __uint_as_float(s2[1]));
         const int64_t o = ((int64_t)pair * (n1_pad / kSub) + (j0 / kSub + wc)) * n0_pad + i0 + wr * 64 + half * 32 + l31;
         row_part[o] = make_float2(b1, b2);
+        const int64_t oc = ((int64_t)pair * (n0_pad / kSub) + (i0 / kSub + wr)) * n1_pad + j0 + wc * 64 + half * 32 + l31;
+        col_part[oc] = col_out;
     }
     __builtin_amdgcn_sched_barrier(0);
     VS_STAMP();

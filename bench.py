@@ -387,6 +387,19 @@ def bench_match(args, rank, world, dist, torch, n=4096, total_pairs=64):
                                frac=ach / MFMA_F16_PEAK_TFLOPS, traffic=None, kernel="dot_top2_kernel",
                                note="algorithmic flops 2*N0*N1*256 per pair = the flops the kernel issues "
                                     "(one fp16 MFMA term; exactness restored by certified rescans)")
+        # what the matrix cores deliver on this chip with real data: a bare MFMA chain from registers
+        # on random operands (the clock drops under the power limit), and on zeros for comparison
+        import ctypes as C
+        from visual_slam_amd import _lib
+        lib = _lib.load()
+        rate = C.c_float(0)
+        if lib.vs_debug_mfma_rate(300, 1, C.byref(rate)) == 0:
+            out["roofline"]["sustained_peak_measured"] = float(rate.value)
+            out["roofline"]["frac_of_sustained_peak"] = ach / float(rate.value)
+            out["roofline"]["sustained_peak_note"] = ("bare v_mfma_f32_32x32x16_f16 chain, operands in registers, "
+                                                      "random data, measured in this run")
+        if lib.vs_debug_mfma_rate(300, 0, C.byref(rate)) == 0:
+            out["roofline"]["zero_operand_peak_measured"] = float(rate.value)
         # library GEMM of the same shape for scale: fp16 bmm through hipBLASLt, scores written to HBM
         a = torch.stack([k[0] for k in keep[:min(pairs, 8)]]).half()
         b = torch.stack([k[1] for k in keep[:min(pairs, 8)]]).half().transpose(1, 2).contiguous()

@@ -245,6 +245,13 @@ int vs_matcher_run_sharded(vs_matcher_handle m, int32_t n_pairs, int32_t row0, f
 int vs_matcher_profile_run(vs_matcher_handle m, int32_t n_pairs, float nn_thresh, float ratio,
                            int32_t iters, float *avg_ms);
 
+/* Measurement aid (no counterpart in the reference): the rate at which the current device issues
+ * v_mfma_f32_32x32x16_f16 back to back from registers, one wave per SIMD on every CU, for about
+ * `millis` milliseconds on random (random_operands != 0) or all-zero operands; *tflops = the
+ * chip-wide fp16 rate of that loop.  On random operands the chip runs into its power limit and the
+ * clock drops, so this is the ceiling a kernel on real data can reach, below the spec peak. */
+int vs_debug_mfma_rate(int32_t millis, int32_t random_operands, float *tflops);
+
 /* One-shot forms with the reference's call shape (host or device pointers). */
 int vs_match_two_way(const float *desc0, int32_t n0, const float *desc1, int32_t n1,
                      float nn_thresh, float ratio, int32_t *out_i, int32_t *out_j, float *out_d,

@@ -20,7 +20,7 @@ SYMBOLS = [
     "vs_ba_set_huber_first", "vs_ba_evaluate", "vs_ba_linearize", "vs_ba_block_count",
     "vs_ba_block_index", "vs_ba_get_reduced_system", "vs_ba_get_landmark_blocks",
     "vs_ba_reduce_buffer", "vs_ba_lm_step", "vs_ba_solve", "vs_ba_set_allreduce",
-    "vs_ba_get_cameras", "vs_ba_get_points", "vs_ba_profile_linearize", "vs_matcher_profile_run",
+    "vs_ba_get_cameras", "vs_ba_get_points", "vs_ba_profile_linearize", "vs_matcher_profile_run", "vs_debug_mfma_rate",
     "vs_matcher_create", "vs_matcher_destroy", "vs_matcher_set_stream", "vs_matcher_set_pair", "vs_matcher_set_pairs",
     "vs_matcher_run", "vs_matcher_run_sharded", "vs_matcher_set_comm", "vs_matcher_set_min_allreduce",
     "vs_matcher_get_matches", "vs_matcher_get_nn", "vs_matcher_get_rescans",

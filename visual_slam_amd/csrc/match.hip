@@ -1553,6 +1553,67 @@ int vs_match_two_way_noalloc(const float *desc0, int32_t n0, const float *desc1,
 
 }  // extern "C"
 
+namespace {
+// bare chain of MFMAs on four accumulators, operands in registers (see vs_debug_mfma_rate)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+mfma_rate_kernel(const float *__restrict__ in, float *__restrict__ out, int iters)
+{
+    half8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = (_Float16)in[(threadIdx.x + i) & 1023]; b[i] = (_Float16)in[(threadIdx.x + 8 + i) & 1023]; }
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[q], 0, 0, 0);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += acc[q][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int vs_debug_mfma_rate(int32_t millis, int32_t random_operands, float *tflops)
+{
+    VS_CHECK(tflops != nullptr && millis > 0 && millis <= 5000, VS_ERR_INVALID, "vs_debug_mfma_rate: bad arguments");
+    int dev = 0, cus = 0;
+    VS_HIP(hipGetDevice(&dev));
+    VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    DevBuf<float> in, out;
+    VS_TRY(in.alloc(1024));
+    VS_TRY(out.alloc((size_t)cus * 256));
+    std::vector<float> h(1024, 0.f);
+    if (random_operands) {
+        unsigned x = 12345u;
+        for (float &v : h) { x = x * 1664525u + 1013904223u; v = (float)((int)(x >> 8) % 2001 - 1000) * 1e-3f; }
+    }
+    VS_HIP(hipMemcpy(in.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    VS_HIP(hipEventCreate(&e0));
+    VS_HIP(hipEventCreate(&e1));
+    const int iters = 20000;                                   // about 1.5 ms per launch
+    const int launches = std::max(2, (int)(millis / 1.5f));
+    int rc = VS_OK;
+    float ms = 0.f;
+    for (int l = 0; l < launches && rc == VS_OK; l++) {      // the last launch, after the clock has settled, is the one timed
+        if (l == launches - 1 && hipEventRecord(e0, nullptr) != hipSuccess) rc = VS_ERR_HIP;
+        hipLaunchKernelGGL(mfma_rate_kernel, dim3(cus), dim3(256), 0, nullptr, in.p, out.p, iters);
+    }
+    if (rc == VS_OK && (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                        hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = VS_ERR_HIP;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != VS_OK) { set_error("vs_debug_mfma_rate: HIP call failed"); return rc; }
+    const double flops = (double)cus * 4 /*waves*/ * 4.0 * iters * (2.0 * 32 * 32 * 16);
+    *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+    return VS_OK;
+}
+
 #ifdef VS_MATCH_STAMPS
 extern "C" int vs_debug_match_stamps(unsigned long long *out)
 {

@@ -2,6 +2,7 @@
 // process (or thread) per GPU.  librccl is opened at run time on first use, so single-GPU callers
 // do not need it and a process that already holds a copy (PyTorch ships one) shares that copy.
 #include <dlfcn.h>
+#include <cstring>
 #include <mutex>
 #include <new>
 

@@ -21,7 +21,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = synth.make_ba_config("c1", seed=21)
-    m = vd.shard_mask(sc.pt, sc.Np, rank, world)
+    m = vd.shard_mask(sc.cam, sc.pt, sc.Np, sc.Nc, rank, world)
     dc = np.full(6 * sc.Nc, 0.3); dp = np.full(3 * sc.Np, 0.3)
     p = orc.Problem(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam[m], sc.pt[m], sc.uv[m])
     s = p.schur(dc=None, dp=dp)
@@ -56,16 +56,24 @@ def test_two_rank_shards_sum_to_the_whole():
     assert total == synth.make_ba_config("c1", seed=21).No      # every edge owned exactly once
 
 
-def test_partition_is_contiguous_and_balanced():
+def test_partition_is_contiguous_in_the_internal_order_and_balanced():
     from visual_slam_amd import dist as vd
     from visual_slam_amd import synth
     sc = synth.make_ba_scene(20, 5000, 5, band=8, seed=3)
+    new2old = vd.landmark_order(sc.cam, sc.pt, sc.Np, sc.Nc)
+    assert np.array_equal(np.sort(new2old), np.arange(sc.Np))
+    first = np.full(sc.Np, sc.Nc); np.minimum.at(first, sc.pt, sc.cam)
+    assert np.all(np.diff(first[new2old]) >= 0)                       # by first camera, stable
     for world in (1, 2, 3, 8):
-        b = vd.partition_landmarks(sc.pt, sc.Np, world)
-        assert b[0] == 0 and b[-1] == sc.Np and np.all(np.diff(b) >= 0)
-        counts = [int(vd.shard_mask(sc.pt, sc.Np, r, world).sum()) for r in range(world)]
+        owner = vd.landmark_owner(sc.cam, sc.pt, sc.Np, sc.Nc, world)
+        assert np.all(np.diff(owner[new2old]) >= 0) and owner.min() == 0 and owner.max() == world - 1
+        counts = [int(vd.shard_mask(sc.cam, sc.pt, sc.Np, sc.Nc, r, world).sum()) for r in range(world)]
         assert sum(counts) == sc.No
         assert max(counts) - min(counts) <= 2 * 8 + sc.No // (50 * world)
+        # a shard sees a contiguous range of cameras: its landmarks start in one stretch of the trajectory
+        if world > 1:
+            lo = [first[owner == r].min() for r in range(world)]
+            assert lo == sorted(lo)
 
 
 def _match_worker(rank, world, port, out):

@@ -73,14 +73,14 @@ def test_two_sharded_handles_solve_like_one(fix_points):
     for r in range(2):
         parts[r].set_allreduce(ar.hook(r))
     steps = run_two_ranks(lambda r: parts[r].lm_step(1e4))
-    bounds = vdist.partition_landmarks(sc.pt, sc.Np, 2)
+    owner = vdist.landmark_owner(sc.cam, sc.pt, sc.Np, sc.Nc, 2)
     for r in range(2):
         d, p, m = steps[r]
         assert rel(d, dw) < 1e-8 and abs(m - mw) < 1e-9 * abs(mw)       # summed scalars are global
-        lo, hi = bounds[r], bounds[r + 1]
+        mine = owner == r
         if not fix_points:
-            assert rel(p[lo:hi], pw[lo:hi]) < 1e-8                      # a rank steps its own landmarks
-            assert not p[:lo].any() and not p[hi:].any()
+            assert rel(p[mine], pw[mine]) < 1e-8                        # a rank steps its own landmarks
+            assert not p[~mine].any()
     assert np.array_equal(steps[0][0], steps[1][0])                     # cameras bitwise equal on both ranks
     assert ar.calls[0] == ar.calls[1] and ar.calls[0] >= 3
     # full solve: identical decisions on both ranks, equal to the unsharded solve
@@ -102,18 +102,18 @@ def test_two_sharded_handles_solve_like_one(fix_points):
 
 
 def test_shard_bounds_of_the_library_follow_the_python_partition():
-    """vs_ba_set_observations_sharded's landmark ranges (read back through which landmarks get a
-    non-zero V^-1) equal visual_slam_amd.dist.partition_landmarks'."""
+    """vs_ba_set_observations_sharded's landmark shards (read back through which landmarks get a
+    non-zero V^-1) equal visual_slam_amd.dist.landmark_owner's."""
     sc = synth.make_ba_scene(30, 1500, 5, band=12, seed=3)
     dp = np.full(3 * sc.Np, 0.1)
     for world in (2, 3, 5):
-        b = vdist.partition_landmarks(sc.pt, sc.Np, world)
+        owner = vdist.landmark_owner(sc.cam, sc.pt, sc.Np, sc.Nc, world)
         for r in range(world):
             part = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=r, world=world)
             part.linearize(None, dp)
             Vinv6, _ = part.landmark_blocks()
             live = np.nonzero(np.abs(Vinv6).max(axis=1) > 0)[0]
-            seen = np.unique(sc.pt[(sc.pt >= b[r]) & (sc.pt < b[r + 1])])
+            seen = np.unique(sc.pt[owner[sc.pt] == r])
             assert np.array_equal(live, seen)
             part.close()
 

@@ -99,6 +99,13 @@ struct vs_ba {
     const void *known_dev_dc = nullptr, *known_dev_dp = nullptr;   // damping pointers already classified as device memory
     DevBuf<real> eval_res, eval_Jc, eval_Jp;                       // staging of vs_ba_evaluate, grown on demand
     int pt_lo = 0, pt_hi = 0;   // landmarks this handle linearises
+    // Landmarks are numbered internally by the first camera that sees them (neighbouring lanes then
+    // read neighbouring camera records and landmark records, and a shard touches a contiguous
+    // camera range).  renum: the internal numbering differs from the caller's; new2old[j] = the
+    // caller's index of internal landmark j.  pts_user / perm_stage: caller-order staging.
+    bool renum = false;
+    DevBuf<int> new2old;
+    DevBuf<real> pts_user, perm_stage;
     DevBuf<real> rank_slots;    // one value per rank: maxima through a sum-only collective
 
     std::vector<int32_t> h_brow, h_bcol;
@@ -161,7 +168,9 @@ int landmark_lds_raise_limit()
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return VS_ERR_HIP; }
     std::lock_guard<std::mutex> lock(m);
     if (!raised[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(landmark_lds_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(landmark_lds_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCamBytesMax) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(landmark_lds_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCamBytesMax) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(backsub_lds_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCamBytesMax) != hipSuccess) {
@@ -175,8 +184,26 @@ int landmark_lds_raise_limit()
 
 size_t cam_lds_bytes(const vs_ba *h) { return h->stage_cams ? (size_t)h->Nc * (sizeof(CamData) + 6 * sizeof(real)) : 0; }
 
+// caller-order rows -> internal order (dst may not alias src)
+int rows_to_internal(vs_ba *h, int width, const real *src, real *dst)
+{
+    const int64_t n = (int64_t)width * h->Np;
+    if (n == 0) return VS_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->Np, width, h->new2old.p, src, dst);
+    return launch_check("gather_rows_kernel");
+}
+// internal rows (stride src_stride, first column src_off) -> caller order, densely packed
+int rows_to_caller(vs_ba *h, int width, const real *src, int src_stride, int src_off, real *dst)
+{
+    const int64_t n = (int64_t)width * h->Np;
+    if (n == 0) return VS_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->Np, width, h->new2old.p, src,
+                       src_stride, src_off, dst);
+    return launch_check("scatter_rows_kernel");
+}
+
 // Builds every index structure from the caller's edge list (host side, once per edge set).
-int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const double *uv)
+int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const double *uv)
 {
     const int Nc = h->Nc, Np = h->Np;
     const int64_t Ng = h->No_global;
@@ -191,8 +218,45 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt, const doubl
     };
     for (int64_t o = 0; o < Ng; o++) {
         VS_CHECK(cam[o] >= 0 && cam[o] < Nc, VS_ERR_INVALID, "observation %lld: camera index %d out of range [0,%d)", (long long)o, cam[o], Nc);
-        VS_CHECK(pt[o] >= 0 && pt[o] < Np, VS_ERR_INVALID, "observation %lld: point index %d out of range [0,%d)", (long long)o, pt[o], Np);
+        VS_CHECK(pt_user[o] >= 0 && pt_user[o] < Np, VS_ERR_INVALID, "observation %lld: point index %d out of range [0,%d)", (long long)o, pt_user[o], Np);
     }
+    // Internal landmark numbering: by the first (lowest) camera that sees the landmark, the caller's
+    // order kept among equals (a counting sort).  Landmarks the reference creates keyframe by
+    // keyframe already come that way, and then nothing is renumbered.
+    std::vector<int32_t> ptn_store;
+    const int32_t *pt = pt_user;
+    {
+        // points held in the internal order of an earlier edge set go back to the caller's order first
+        if (h->renum && h->have_pts) {
+            VS_TRY(rows_to_caller(h, 3, h->pts.p, 3, 0, h->pts_user.p));
+            VS_HIP(hipMemcpyAsync(h->pts.p, h->pts_user.p, 3 * (size_t)Np * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
+            VS_HIP(hipStreamSynchronize(h->stream));
+        }
+        h->renum = false;
+        std::vector<int32_t> first_cam((size_t)Np, Nc);
+        for (int64_t o = 0; o < Ng; o++) first_cam[pt_user[o]] = std::min(first_cam[pt_user[o]], cam[o]);
+        bool sorted = true;
+        for (int j = 1; j < Np && sorted; j++) sorted = first_cam[j - 1] <= first_cam[j];
+        if (!sorted && getenv("VS_BA_NO_RENUMBER") == nullptr) {
+            std::vector<int32_t> start((size_t)Nc + 2, 0), new2old((size_t)Np), old2new((size_t)Np);
+            for (int j = 0; j < Np; j++) start[first_cam[j] + 1]++;
+            for (int c = 0; c <= Nc; c++) start[c + 1] += start[c];
+            for (int j = 0; j < Np; j++) { const int32_t q = start[first_cam[j]]++; new2old[q] = j; old2new[j] = q; }
+            ptn_store.resize((size_t)std::max<int64_t>(Ng, 1));
+            for (int64_t o = 0; o < Ng; o++) ptn_store[o] = old2new[pt_user[o]];
+            pt = ptn_store.data();
+            VS_TRY(h->new2old.upload(new2old.data(), new2old.size(), h->stream));
+            if (h->pts_user.n < 3 * (size_t)Np) VS_TRY(h->pts_user.alloc(3 * (size_t)std::max(Np, 1)));
+            if (h->perm_stage.n < 9 * (size_t)Np) VS_TRY(h->perm_stage.alloc(9 * (size_t)std::max(Np, 1)));
+            h->renum = true;
+            if (h->have_pts) {   // the points were set before the edges: bring them into the internal order
+                VS_HIP(hipMemcpyAsync(h->pts_user.p, h->pts.p, 3 * (size_t)Np * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
+                VS_TRY(rows_to_internal(h, 3, h->pts_user.p, h->pts.p));
+            }
+            VS_HIP(hipStreamSynchronize(h->stream));
+        }
+    }
+    lap("landmark numbering");
     // global landmark CSR
     std::vector<int64_t> gptr((size_t)Np + 1, 0);
     for (int64_t o = 0; o < Ng; o++) gptr[pt[o] + 1]++;
@@ -515,8 +579,13 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
                            (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->lm_cam_lo.p,
                            h->lm_cam_span, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
+    else if (h->lds_cam_grid > 0 && pd.lam_p && pd.lam_map)
+        hipLaunchKernelGGL(landmark_lds_kernel<true>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
+                           (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
+                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
+                           pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else if (h->lds_cam_grid > 0)
-        hipLaunchKernelGGL(landmark_lds_kernel, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
+        hipLaunchKernelGGL(landmark_lds_kernel<false>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
                            (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
                            h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
                            pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
@@ -849,7 +918,12 @@ int vs_ba_set_cameras(vs_ba_handle h, const double *t, const double *rpy)
 int vs_ba_set_points(vs_ba_handle h, const double *xyz)
 {
     VS_CHECK(h && xyz, VS_ERR_INVALID, "null argument");
-    VS_HIP(hipMemcpyAsync(h->pts.p, xyz, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+    if (h->renum) {
+        VS_HIP(hipMemcpyAsync(h->pts_user.p, xyz, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+        VS_TRY(rows_to_internal(h, 3, h->pts_user.p, h->pts.p));
+    } else {
+        VS_HIP(hipMemcpyAsync(h->pts.p, xyz, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+    }
     VS_HIP(hipStreamSynchronize(h->stream));
     h->have_pts = true; h->linearized = false; h->have_scale = false; h->prelin = false;
     return VS_OK;
@@ -952,6 +1026,7 @@ int vs_ba_linearize(vs_ba_handle h, const double *damp_c, const double *damp_p)
     PointDamping pd{ nullptr, nullptr, 1.0, 0.0, 0.0 };
     const real *lc = nullptr;
     VS_TRY(resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, s, &pd.lam_p, &h->known_dev_dp));
+    pd.lam_map = h->renum ? h->new2old.p : nullptr;   // the caller's array is read through the renumbering
     VS_TRY(resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, s, &lc, &h->known_dev_dc));
     // the camera damping is added as the diagonal blocks are stored (no extra pass); of the shards
     // of a multi-GPU problem only rank 0 adds it, so that the cross-GPU sum carries it once
@@ -968,6 +1043,7 @@ int vs_ba_profile_linearize(vs_ba_handle h, const double *damp_c, const double *
     for (int k = 0; k < 6; k++) avg_ms[k] = 0.f;
     int rc = vs_ba_linearize(h, damp_c, damp_p);   // warm-up
     PointDamping pd{ nullptr, nullptr, 1.0, 0.0, 0.0 };
+    pd.lam_map = h->renum ? h->new2old.p : nullptr;
     const real *lc = nullptr;
     if (rc == VS_OK) rc = resident_or_upload(damp_p, 3 * (size_t)h->Np, h->lam_p_user, h->stream, &pd.lam_p, &h->known_dev_dp);
     if (rc == VS_OK) rc = resident_or_upload(damp_c, 6 * (size_t)h->Nc, h->lam_c_user, h->stream, &lc, &h->known_dev_dc);
@@ -1026,8 +1102,20 @@ int vs_ba_get_landmark_blocks(vs_ba_handle h, double *Vinv6, double *gp)
     VS_CHECK(h->linearized, VS_ERR_STATE, "call vs_ba_linearize first");
     hipStream_t s = h->stream;
     const size_t pitch = kRec * sizeof(real);
-    if (Vinv6) VS_HIP(hipMemcpy2DAsync(Vinv6, 6 * sizeof(real), h->lmrec.p + 3, pitch, 6 * sizeof(real), (size_t)h->Np, hipMemcpyDefault, s));
-    if (gp) VS_HIP(hipMemcpy2DAsync(gp, 3 * sizeof(real), h->lmrec.p + 9, pitch, 3 * sizeof(real), (size_t)h->Np, hipMemcpyDefault, s));
+    if (h->renum) {   // caller's landmark order through the staging buffer: [Vinv 6 Np | g_p 3 Np]
+        const size_t np = (size_t)h->Np;
+        if (Vinv6) {
+            VS_TRY(rows_to_caller(h, 6, h->lmrec.p, kRec, 3, h->perm_stage.p));
+            VS_HIP(hipMemcpyAsync(Vinv6, h->perm_stage.p, 6 * np * sizeof(real), hipMemcpyDefault, s));
+        }
+        if (gp) {
+            VS_TRY(rows_to_caller(h, 3, h->lmrec.p, kRec, 9, h->perm_stage.p + 6 * np));
+            VS_HIP(hipMemcpyAsync(gp, h->perm_stage.p + 6 * np, 3 * np * sizeof(real), hipMemcpyDefault, s));
+        }
+    } else {
+        if (Vinv6) VS_HIP(hipMemcpy2DAsync(Vinv6, 6 * sizeof(real), h->lmrec.p + 3, pitch, 6 * sizeof(real), (size_t)h->Np, hipMemcpyDefault, s));
+        if (gp) VS_HIP(hipMemcpy2DAsync(gp, 3 * sizeof(real), h->lmrec.p + 9, pitch, 3 * sizeof(real), (size_t)h->Np, hipMemcpyDefault, s));
+    }
     VS_HIP(hipStreamSynchronize(s));
     return VS_OK;
 }
@@ -1070,7 +1158,11 @@ int vs_ba_lm_step(vs_ba_handle h, double radius, double *dcam, double *dpt, doub
     VS_CHECK(!fail, VS_ERR_NUMERIC, "reduced camera system is not positive definite");
     hipStream_t s = h->stream;
     if (dcam) VS_HIP(hipMemcpyAsync(dcam, h->dcam.p, 6 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, s));
-    if (dpt) VS_HIP(hipMemcpyAsync(dpt, h->dpt.p, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, s));
+    if (dpt) {
+        const real *src = h->dpt.p;
+        if (h->renum) { VS_TRY(rows_to_caller(h, 3, h->dpt.p, 3, 0, h->perm_stage.p)); src = h->perm_stage.p; }
+        VS_HIP(hipMemcpyAsync(dpt, src, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, s));
+    }
     VS_HIP(hipStreamSynchronize(s));
     if (mcc) *mcc = sc.mcc;
     return VS_OK;
@@ -1183,7 +1275,12 @@ int vs_ba_get_points(vs_ba_handle h, double *xyz)
 {
     VS_CHECK(h && xyz, VS_ERR_INVALID, "null argument");
     VS_CHECK(h->have_pts, VS_ERR_STATE, "points not set");
-    VS_HIP(hipMemcpyAsync(xyz, h->pts.p, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+    const real *src = h->pts.p;
+    if (h->renum) {
+        VS_TRY(rows_to_caller(h, 3, h->pts.p, 3, 0, h->pts_user.p));
+        src = h->pts_user.p;
+    }
+    VS_HIP(hipMemcpyAsync(xyz, src, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
     VS_HIP(hipStreamSynchronize(h->stream));
     return VS_OK;
 }

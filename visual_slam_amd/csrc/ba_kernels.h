@@ -222,6 +222,7 @@ struct PointDamping {
     const real *lam_p;
     const real *scale_p;
     real radius, min_d, max_d;
+    const int *lam_map;     // lam_p is in the caller's landmark numbering: entry of landmark j at lam_map[j] (NULL: j)
 };
 
 struct HuberObs {
@@ -283,7 +284,8 @@ __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int
                                                const int *__restrict__ lcam, const real *__restrict__ luv,
                                                const HuberObs &hub, const PointDamping &damp,
                                                double2 *rec, real *__restrict__ Vdiag,
-                                               real *__restrict__ hub_w, int c_first, double2 uv_first, CamFetch fetch)
+                                               real *__restrict__ hub_w, int c_first, double2 uv_first, CamFetch fetch,
+                                               int jd = -1)
 {
     real acc[10];                                      // V (6), g (3), cost
 #pragma unroll
@@ -294,7 +296,9 @@ __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int
     real dmp[3] = { real(0), real(0), real(0) };
     auto load_damping = [&]() {
         const real *src = damp.lam_p ? damp.lam_p : damp.scale_p;
-        if (src) { dmp[0] = src[3 * j]; dmp[1] = src[3 * j + 1]; dmp[2] = src[3 * j + 2]; }
+        // jd >= 0: the caller has already fetched this landmark's index in the damping array
+        const int64_t jj = jd >= 0 ? jd : (damp.lam_p && damp.lam_map ? damp.lam_map[j] : j);
+        if (src) { dmp[0] = src[3 * jj]; dmp[1] = src[3 * jj + 1]; dmp[2] = src[3 * jj + 2]; }
     };
     if (EARLY_DAMP && j < Np && sl == 0) load_damping();
     if (j < Np) {
@@ -471,6 +475,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
 // writes that workgroup's cost partial, so the partials and their sum are the same.
 constexpr int kCamLdsReals = 14;
 constexpr int kLmBigThreads = 1024;
+template <bool MAPPED>   // explicit per-landmark damping in the caller's numbering (read through damp.lam_map)
 __global__ void __launch_bounds__(kLmBigThreads)
 landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict__ prep_t,
                     const real *__restrict__ prep_rpy, CamData *__restrict__ cams_out,
@@ -500,19 +505,29 @@ landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict_
     // Two memory latencies precede a landmark's arithmetic (its observation range and position,
     // then its first observation).  Both are taken off the critical path: the range and position
     // are fetched two tiles ahead, the first observation one tile ahead.
-    struct Own { int j, b, e; real P[3]; };
-    auto load_own = [&](int t0, Own &o) {
+    struct Own { int b, e; real P[3]; };                 // the landmark index itself follows from the tile
+    auto landmark_of = [&](int t0) {
         const int tile = t0 + group;
-        o.j = tile < n_tiles ? tile * kLmPerBlock + tg / kLpl : Np;
+        return tile < n_tiles ? tile * kLmPerBlock + tg / kLpl : Np;
+    };
+    auto load_own = [&](int t0, Own &o) {
+        const int j = landmark_of(t0);
         o.b = 0; o.e = 0; o.P[0] = o.P[1] = o.P[2] = real(0);
-        if (o.j < Np) {
-            o.b = pt_ptr[o.j]; o.e = pt_ptr[o.j + 1];
-            o.P[0] = pts[3 * o.j]; o.P[1] = pts[3 * o.j + 1]; o.P[2] = pts[3 * o.j + 2];
+        if (j < Np) {
+            o.b = pt_ptr[j]; o.e = pt_ptr[j + 1];
+            o.P[0] = pts[3 * j]; o.P[1] = pts[3 * j + 1]; o.P[2] = pts[3 * j + 2];
         }
     };
     auto load_first = [&](const Own &o, int &c, double2 &uv) {
         c = 0; uv = make_double2(0, 0);
         if (o.b + sl < o.e) { c = lcam[o.b + sl]; uv = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)(o.b + sl)); }
+    };
+    // MAPPED: the landmark's index in the caller's damping array, fetched one tile ahead
+    int jd_cur = -1, jd_nxt = -1;
+    auto load_map = [&](int t0, int &jd) {
+        const int j = landmark_of(t0);
+        jd = -1;
+        if (MAPPED && j < Np && sl == 0) jd = damp.lam_map[j];
     };
     const int stride = gridDim.x * kGroups;
     Own cur, nxt;
@@ -521,18 +536,20 @@ landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict_
     load_own(blockIdx.x * kGroups, cur);
     load_own(blockIdx.x * kGroups + stride, nxt);
     load_first(cur, c_cur, uv_cur);
+    load_map(blockIdx.x * kGroups, jd_cur);
     for (int t0 = blockIdx.x * kGroups; t0 < n_tiles; t0 += stride) {
         Own nn;
         load_own(t0 + 2 * stride, nn);
         load_first(nxt, c_nxt, uv_nxt);
+        load_map(t0 + stride, jd_nxt);
         double2 rec[6] = {};
-        real v = landmark_lanes<false>(cur.j, sl, Np, cur.b, cur.e, cur.P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_cur, uv_cur,
+        real v = landmark_lanes<false>(landmark_of(t0), sl, Np, cur.b, cur.e, cur.P, K, lcam, luv, hub, damp, rec, Vdiag, hub_w, c_cur, uv_cur,
                                 [&](int c, CamData &cd) {
                                     const double2 *src = scam + 7 * c;
                                     double2 *dst = reinterpret_cast<double2 *>(&cd);
 #pragma unroll
                                     for (int q = 0; q < 7; q++) dst[q] = src[q];
-                                });
+                                }, jd_cur);
         if (t0 + group < n_tiles)
             store_records(rec_stage + wave * kRecStage, lane, (t0 + group) * kLmPerBlock + (tg / kWave) * kRecsPerWave, Np, rec, lmrec);
         // per-group sum in the order block_sum_256 takes it
@@ -543,7 +560,7 @@ landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict_
         __syncthreads();
         if (tg == 0 && t0 + group < n_tiles)
             cost_partial[t0 + group] = red[4 * group] + red[4 * group + 1] + red[4 * group + 2] + red[4 * group + 3];
-        cur = nxt; nxt = nn; c_cur = c_nxt; uv_cur = uv_nxt;
+        cur = nxt; nxt = nn; c_cur = c_nxt; uv_cur = uv_nxt; jd_cur = jd_nxt;
     }
 }
 
@@ -1329,6 +1346,27 @@ __global__ void max_of_kernel(int n, const real *__restrict__ in, real *__restri
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
     if (threadIdx.x == 0) *out = m;
+}
+
+// Landmark renumbering at the boundary (the library numbers landmarks by the first camera that
+// sees them; map[j] = the caller's index of internal landmark j).  Rows of `width` reals:
+//   gather:  dst[j] (stride width)            = src[map[j]] (stride width)
+//   scatter: dst[map[j]] (stride width)       = src[j] (stride src_stride, starting at src_off)
+__global__ void gather_rows_kernel(int Np, int width, const int *__restrict__ map, const real *__restrict__ src,
+                                   real *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)width * Np) return;
+    const int j = (int)(i / width), k = (int)(i - (int64_t)j * width);
+    dst[i] = src[(int64_t)width * map[j] + k];
+}
+__global__ void scatter_rows_kernel(int Np, int width, const int *__restrict__ map, const real *__restrict__ src,
+                                    int src_stride, int src_off, real *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)width * Np) return;
+    const int j = (int)(i / width), k = (int)(i - (int64_t)j * width);
+    dst[(int64_t)width * map[j] + k] = src[(int64_t)src_stride * j + src_off + k];
 }
 
 // Zeroes the points outside [pt_lo, pt_hi) (the shard sum that follows gathers all points).

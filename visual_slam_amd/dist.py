@@ -1,14 +1,22 @@
 """Multi-GPU plumbing for the BA path: one process per GPU, landmarks sharded across ranks, the
 reduced camera system summed with one all-reduce (RCCL through torch.distributed's "nccl" backend
-on GPUs; "gloo" in the CPU tests).  The reference has no distributed path; the partition rule
-below is the one libvslam_hip.so applies in vs_ba_set_observations_sharded.
+on GPUs; "gloo" in the CPU tests).  The reference has no distributed path; the numbering and
+partition rules below are the ones libvslam_hip.so applies in vs_ba_set_observations_sharded.
 """
 import numpy as np
 
 
+def landmark_order(cam, pt, n_points, n_cams):
+    """The library's internal landmark numbering: landmarks by the first (lowest) camera that sees
+    them, the caller's order kept among equals; landmarks nobody sees last.  Returns new2old."""
+    first = np.full(n_points, n_cams, dtype=np.int64)
+    np.minimum.at(first, np.asarray(pt), np.asarray(cam))
+    return np.argsort(first, kind="stable")
+
+
 def partition_landmarks(pt, n_points, world):
-    """Contiguous landmark ranges balanced by observation count.
-    Returns an array of world+1 landmark boundaries; rank r owns [b[r], b[r+1])."""
+    """Contiguous landmark ranges balanced by observation count, for landmarks that already are in
+    the internal numbering.  Returns world+1 boundaries; rank r owns [b[r], b[r+1])."""
     pt = np.asarray(pt)
     counts = np.bincount(pt, minlength=n_points).astype(np.int64)
     ptr = np.concatenate([[0], np.cumsum(counts)])
@@ -21,10 +29,20 @@ def partition_landmarks(pt, n_points, world):
     return np.maximum.accumulate(bounds)
 
 
-def shard_mask(pt, n_points, rank, world):
-    b = partition_landmarks(pt, n_points, world)
-    pt = np.asarray(pt)
-    return (pt >= b[rank]) & (pt < b[rank + 1])
+def landmark_owner(cam, pt, n_points, n_cams, world):
+    """Rank that linearises each landmark (caller's numbering): contiguous ranges of the internal
+    numbering, balanced by observation count."""
+    new2old = landmark_order(cam, pt, n_points, n_cams)
+    old2new = np.empty(n_points, dtype=np.int64)
+    old2new[new2old] = np.arange(n_points)
+    b = partition_landmarks(old2new[np.asarray(pt)], n_points, world)
+    owner_new = np.searchsorted(b[1:], np.arange(n_points), side="right")
+    return np.minimum(owner_new, world - 1)[old2new]
+
+
+def shard_mask(cam, pt, n_points, n_cams, rank, world):
+    """Edges of the caller's list that rank `rank` linearises."""
+    return landmark_owner(cam, pt, n_points, n_cams, world)[np.asarray(pt)] == rank
 
 
 class _DevArray:

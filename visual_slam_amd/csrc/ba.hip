@@ -505,9 +505,11 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         }
     }
 
-    // Neither: every camera still fits the LDS of a CU as one array (one persistent workgroup per CU)
+    // Up to about 1200 cameras every camera fits the LDS of a CU as one array (one persistent
+    // workgroup per CU, no separate camera pass): preferred over the range staging where both apply
+    // (config 4 in keyframe order: 31 us against 33 + 4 us for range staging and its camera pass)
     h->lds_cam_grid = 0;
-    if (!h->stage_cams && h->lm_cam_span == 0 && (size_t)Nc * kCamLdsReals * sizeof(real) <= kLdsCamBytesMax &&
+    if (!h->stage_cams && (size_t)Nc * kCamLdsReals * sizeof(real) <= kLdsCamBytesMax &&
         getenv("VS_BA_NO_LDS_CAMS") == nullptr) {
         int dev = 0, cus = 0;
         VS_HIP(hipGetDevice(&dev));
@@ -565,30 +567,36 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     real *vdiag = want_vdiag ? h->Vdiag.p : nullptr;   // diag(V): only the Jacobi scaling pass reads it
     auto mark = [&](int i) { if (h->prof_ev) (void)hipEventRecord(h->prof_ev[i], h->stream); };
     mark(0);
-    // few cameras: the landmark kernel builds the camera records itself (no separate pass)
-    if (!h->stage_cams && h->lds_cam_grid == 0) VS_TRY(prep_cameras(h, t, rpy));
+    // Landmark kernel: all cameras in the workgroup's LDS (few cameras), all cameras in a CU's LDS
+    // (persistent workgroups), this workgroup's camera range in LDS, or gathered.  The two
+    // all-camera forms build the camera records themselves (no separate pass).  Explicit damping
+    // in the caller's landmark numbering costs the persistent form more than range staging plus
+    // the camera pass (config 4: 39.6 against 36.1 + 2 us), so that case goes to range staging.
+    const bool mapped = pd.lam_p && pd.lam_map;
+    const bool use_lds = h->lds_cam_grid > 0 && !(mapped && h->lm_cam_span > 0);
+    if (!h->stage_cams && !use_lds) VS_TRY(prep_cameras(h, t, rpy));
     mark(1);
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
         hipLaunchKernelGGL(landmark_kernel<1>, dim3(h->n_lm4_blocks), dim3(kLmThreads), lds, h->stream,
                            h->Np, h->Nc, h->K, (const CamData *)nullptr, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p,
                            h->hub, (const int *)nullptr, 0, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
+    else if (use_lds && mapped)
+        hipLaunchKernelGGL(landmark_lds_kernel<true>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
+                           (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
+                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
+                           pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
+    else if (use_lds)
+        hipLaunchKernelGGL(landmark_lds_kernel<false>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
+                           (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
+                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
+                           pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else if (h->lm_cam_span > 0)
         hipLaunchKernelGGL(landmark_kernel<2>, dim3(h->n_lm4_blocks), dim3(kLmThreads),
                            (size_t)h->lm_cam_span * sizeof(CamData), h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
                            (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->lm_cam_lo.p,
                            h->lm_cam_span, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
-    else if (h->lds_cam_grid > 0 && pd.lam_p && pd.lam_map)
-        hipLaunchKernelGGL(landmark_lds_kernel<true>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
-                           (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
-                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
-                           pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
-    else if (h->lds_cam_grid > 0)
-        hipLaunchKernelGGL(landmark_lds_kernel<false>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
-                           (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
-                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
-                           pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else
         hipLaunchKernelGGL(landmark_kernel<0>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,

@@ -207,6 +207,8 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
 {
     const int Nc = h->Nc, Np = h->Np;
     const int64_t Ng = h->No_global;
+    h->have_obs = false;     // a call that fails part-way leaves no usable edge set behind
+    h->linearized = false;
     // VS_BA_BUILD_TIMING=1 prints where the time of this function goes (developer knob)
     const bool timing = getenv("VS_BA_BUILD_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();

@@ -99,6 +99,7 @@ struct vs_ba {
     const void *known_dev_dc = nullptr, *known_dev_dp = nullptr;   // damping pointers already classified as device memory
     DevBuf<real> eval_res, eval_Jc, eval_Jp;                       // staging of vs_ba_evaluate, grown on demand
     int pt_lo = 0, pt_hi = 0;   // landmarks this handle linearises
+    int tile_lo = 0, tile_hi = 0;   // landmark-kernel tiles (kLmPerBlock landmarks each) that hold them
     // Landmarks are numbered internally by the first camera that sees them (neighbouring lanes then
     // read neighbouring camera records and landmark records, and a shard touches a contiguous
     // camera range).  renum: the internal numbering differs from the caller's; new2old[j] = the
@@ -486,6 +487,12 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
     for (int k = 0; k < nb_off; k++) h->n_multi_off += oi_ptr[k + 1] - oi_ptr[k] != 1; // finalize zeroes them
     h->n_lm_blocks = div_up(Np, kLmThreads);
     h->n_lm4_blocks = div_up(Np, kLmPerBlock);
+    // a shard's landmark kernel runs over its own tiles only; the records and cost partials of the
+    // other tiles are zeroed once (below) and never written
+    h->tile_lo = h->world > 1 ? pt_lo / kLmPerBlock : 0;
+    h->tile_hi = h->world > 1 ? std::max(h->tile_lo + 1, div_up(pt_hi, kLmPerBlock)) : h->n_lm4_blocks;
+    h->tile_hi = std::min(h->tile_hi, std::max(h->n_lm4_blocks, 1));
+    if (h->tile_lo >= h->tile_hi) h->tile_lo = std::max(0, h->tile_hi - 1);
     h->stage_cams = (size_t)Nc * (sizeof(CamData) + 6 * sizeof(real)) <= 48 * 1024;
     // More cameras than fit LDS: when the cameras seen by the landmarks of one landmark-kernel
     // workgroup span a short index range (keyframes in time order), that range is staged instead.
@@ -517,7 +524,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         VS_HIP(hipGetDevice(&dev));
         VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         VS_TRY(landmark_lds_raise_limit());
-        h->lds_cam_grid = std::max(1, std::min(cus, div_up(h->n_lm4_blocks, kLmBigThreads / kLmThreads)));
+        h->lds_cam_grid = std::max(1, std::min(cus, div_up(h->tile_hi - h->tile_lo, kLmBigThreads / kLmThreads)));
     }
 
     lap("work items");
@@ -547,6 +554,9 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
     VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
     VS_TRY(h->off_partial.alloc((size_t)std::max(h->n_off_items, 1) * kOffVals));
     VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm4_blocks, 1)));
+    VS_HIP(hipMemsetAsync(h->cost_partial.p, 0, (size_t)std::max(h->n_lm4_blocks, 1) * sizeof(real), s));
+    if (h->lmrec.p) VS_HIP(hipMemsetAsync(h->lmrec.p, 0, h->lmrec.n * sizeof(real), s));
+    if (h->Vdiag.p) VS_HIP(hipMemsetAsync(h->Vdiag.p, 0, h->Vdiag.n * sizeof(real), s));
     VS_TRY(h->mcc_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
     h->red_len = (int64_t)Nc * 36 + (int64_t)nb_off * 36 + 18 * (int64_t)Nc + 1;
     VS_TRY(h->red.alloc((size_t)h->red_len));
@@ -579,31 +589,32 @@ int linearize(vs_ba *h, const real *t, const real *rpy, const real *pts, PointDa
     if (!h->stage_cams && !use_lds) VS_TRY(prep_cameras(h, t, rpy));
     mark(1);
     const size_t lds = cam_lds_bytes(h);
+    const int n_tiles = std::max(1, h->tile_hi - h->tile_lo);
     if (h->stage_cams)
-        hipLaunchKernelGGL(landmark_kernel<1>, dim3(h->n_lm4_blocks), dim3(kLmThreads), lds, h->stream,
+        hipLaunchKernelGGL(landmark_kernel<1>, dim3(n_tiles), dim3(kLmThreads), lds, h->stream,
                            h->Np, h->Nc, h->K, (const CamData *)nullptr, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p,
-                           h->hub, (const int *)nullptr, 0, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
+                           h->hub, (const int *)nullptr, 0, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p, h->tile_lo);
     else if (use_lds && mapped)
         hipLaunchKernelGGL(landmark_lds_kernel<true>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
                            (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
-                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
+                           h->Np, h->Nc, h->tile_lo, h->tile_hi, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
                            pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else if (use_lds)
         hipLaunchKernelGGL(landmark_lds_kernel<false>, dim3(h->lds_cam_grid), dim3(kLmBigThreads),
                            (size_t)h->Nc * kCamLdsReals * sizeof(real), h->stream,
-                           h->Np, h->Nc, h->n_lm4_blocks, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
+                           h->Np, h->Nc, h->tile_lo, h->tile_hi, h->K, t, rpy, h->cams.p, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub,
                            pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
     else if (h->lm_cam_span > 0)
-        hipLaunchKernelGGL(landmark_kernel<2>, dim3(h->n_lm4_blocks), dim3(kLmThreads),
+        hipLaunchKernelGGL(landmark_kernel<2>, dim3(n_tiles), dim3(kLmThreads),
                            (size_t)h->lm_cam_span * sizeof(CamData), h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
                            (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->lm_cam_lo.p,
-                           h->lm_cam_span, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
+                           h->lm_cam_span, pd, h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p, h->tile_lo);
     else
-        hipLaunchKernelGGL(landmark_kernel<0>, dim3(h->n_lm4_blocks), dim3(kLmThreads), 0, h->stream,
+        hipLaunchKernelGGL(landmark_kernel<0>, dim3(n_tiles), dim3(kLmThreads), 0, h->stream,
                            h->Np, h->Nc, h->K, h->cams.p, (const real *)nullptr, (const real *)nullptr,
                            (CamData *)nullptr, pts, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, (const int *)nullptr, 0, pd,
-                           h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p);
+                           h->lmrec.p, vdiag, h->hub_w.p, h->cost_partial.p, h->tile_lo);
     VS_TRY(launch_check("landmark_kernel"));
     mark(2);
     {

@@ -426,14 +426,16 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                 const real *__restrict__ pts, const int *__restrict__ pt_ptr,
                 const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
                 const int *__restrict__ cam_lo, int cam_span, PointDamping damp, real *__restrict__ lmrec, real *__restrict__ Vdiag,
-                real *__restrict__ hub_w, real *__restrict__ cost_partial)
+                real *__restrict__ hub_w, real *__restrict__ cost_partial, int tile0)
 {
+    // a landmark shard launches only the tiles that hold its landmarks: workgroup b is tile tile0 + b
+    const int tile = tile0 + (int)blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     CamData *scams = reinterpret_cast<CamData *>(smem_raw);
     __shared__ real red[4];
     __shared__ __attribute__((aligned(16))) real rec_stage[(kLmThreads / kWave) * kRecStage];
     // the landmark's own data first: these loads are in flight while the cameras are staged
-    const int j = blockIdx.x * kLmPerBlock + (int)threadIdx.x / kLpl;
+    const int j = tile * kLmPerBlock + (int)threadIdx.x / kLpl;
     const int sl = threadIdx.x & (kLpl - 1);
     real P[3] = { 0, 0, 0 };
     int b = 0, e = 0;
@@ -444,7 +446,7 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
     if (STAGE == 1) stage_all_cameras(scams, Nc, cams, prep_t, prep_rpy, cams_out);
     int lo = 0;
     if (STAGE == 2) {
-        lo = cam_lo[blockIdx.x];
+        lo = cam_lo[tile];
         const int cnt = min(cam_span, Nc - lo);
         const double2 *src = reinterpret_cast<const double2 *>(cams + lo);
         double2 *dst = reinterpret_cast<double2 *>(scams);
@@ -459,10 +461,10 @@ landmark_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams,
                                      [&](int c, CamData &cd) { if (STAGE == 0) load_cam(cams, c, cd); else cd = scams[c - lo]; });
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        store_records(rec_stage + wave * kRecStage, lane, blockIdx.x * kLmPerBlock + wave * kRecsPerWave, Np, rec, lmrec);
+        store_records(rec_stage + wave * kRecStage, lane, tile * kLmPerBlock + wave * kRecsPerWave, Np, rec, lmrec);
     }
     const real s = block_sum_256(cost, red);
-    if (threadIdx.x == 0) cost_partial[blockIdx.x] = s;
+    if (threadIdx.x == 0) cost_partial[tile] = s;
 }
 
 // The landmark kernel for camera counts whose records fit LDS only as a whole-CU array (up to
@@ -477,7 +479,7 @@ constexpr int kCamLdsReals = 14;
 constexpr int kLmBigThreads = 1024;
 template <bool MAPPED>   // explicit per-landmark damping in the caller's numbering (read through damp.lam_map)
 __global__ void __launch_bounds__(kLmBigThreads)
-landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict__ prep_t,
+landmark_lds_kernel(int Np, int Nc, int tile0, int n_tiles, Intr K, const real *__restrict__ prep_t,
                     const real *__restrict__ prep_rpy, CamData *__restrict__ cams_out,
                     const real *__restrict__ pts, const int *__restrict__ pt_ptr,
                     const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub,
@@ -533,11 +535,13 @@ landmark_lds_kernel(int Np, int Nc, int n_tiles, Intr K, const real *__restrict_
     Own cur, nxt;
     int c_cur, c_nxt;
     double2 uv_cur, uv_nxt;
-    load_own(blockIdx.x * kGroups, cur);
-    load_own(blockIdx.x * kGroups + stride, nxt);
+    // tiles [tile0, n_tiles): a landmark shard walks only the tiles that hold its landmarks
+    const int t_first = tile0 + blockIdx.x * kGroups;
+    load_own(t_first, cur);
+    load_own(t_first + stride, nxt);
     load_first(cur, c_cur, uv_cur);
-    load_map(blockIdx.x * kGroups, jd_cur);
-    for (int t0 = blockIdx.x * kGroups; t0 < n_tiles; t0 += stride) {
+    load_map(t_first, jd_cur);
+    for (int t0 = t_first; t0 < n_tiles; t0 += stride) {
         Own nn;
         load_own(t0 + 2 * stride, nn);
         load_first(nxt, c_nxt, uv_nxt);

@@ -44,8 +44,15 @@ constexpr int kBM = 64 * kWR, kBN = 64 * kWC;      // workgroup tile
 #endif
 constexpr int kBK = VS_BK;             // halfs per K-step (one ring stage)
 #ifndef VS_RING
-#define VS_RING 2
+#define VS_RING 4
 #endif
+// Four stages (64 KB) + the transposition areas = 98 KB: ONE workgroup per CU, one wave per SIMD.
+// The earlier shape (two stages, two workgroups per CU, 0.57 ms per 64-pair batch against 0.76 ms
+// now) returned a few wrong nearest neighbours per 4096 x 4096 pair whenever a grid put more than
+// four waves on a CU: rarely a 1 KiB LDS-DMA piece was read before it had landed although its wave
+// had waited for vmcnt(0) and the workgroup had passed the barrier (tools/match_stress3.py counts
+// them against the exact CPU argmin; a three-stage ring failed the same way even alone on a CU,
+// a delay after the barrier made the errors rarer).  This shape ran that stress clean.
 constexpr int kRing = VS_RING;         // LDS ring stages (kRing - 1 K-steps of lookahead)
 constexpr int kSub = 64;               // rows/cols covered by one wave = granularity of partials
 constexpr float kScale = 256.0f;       // descriptor prescale (2^8), dot prescale 2^16
@@ -250,7 +257,7 @@ constexpr int kDotLds = kRing * kStageBytes;
 #else
 constexpr int kDotLds = kRing * kStageBytes + 4 * 32 * kTS * 4;
 #endif
-static_assert(2 * kDotLds <= 160 * 1024, "two workgroups per CU");
+static_assert(kDotLds <= 160 * 1024, "the ring and the transposition areas fit the CU's LDS");
 
 // One workgroup = one band: kBM rows of desc0 of one frame pair against `tiles_per_wg` consecutive
 // kBN-column tiles of desc1.  4 waves, each a 64 x 64 sub-tile as 2 x 2 MFMA 32x32x16 f16 tiles.
@@ -370,16 +377,11 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         // Wait until this wave's share of stage s has landed; after the barrier every wave's has,
         // and every wave has finished reading ring slot (s - 1) % kRing, which is refilled next.
         // Loads return in issue order, so allowing the DMAs of the kRing - 2 younger stages to
-        // stay in flight retires stage s; the first step of a band and the tail of the band (fewer
-        // younger stages exist) drain fully.
-        // The first step of a later tile follows the two partial stores of the tile before it: they
-        // are the youngest vector-memory operations (the counter retires loads and stores in issue
-        // order), so they may stay in flight too -- waiting for them would expose a store latency
-        // per tile.
-        if (kt == 0 && tc > c_begin) {
-            if (s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInflight + 2) : "memory");
-        } else if (kt == 0 || s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stay in flight retires stage s; the first step of a tile (the epilogue's stores sit
+        // between the DMAs, and loads and stores do not retire in order relative to each other:
+        // a counted wait with stores pending could let a DMA piece slip) and the tail of the band
+        // (fewer younger stages exist) drain fully.
+        if (kt == 0 || s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInflight) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);

@@ -281,7 +281,10 @@ __device__ unsigned long long g_match_stamps[4 * 64];
 #endif
 
 template <bool MASKED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef VS_DOT_WPE
+#define VS_DOT_WPE 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VS_DOT_WPE, VS_DOT_WPE)))
 dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b16,
                 const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
                 const int2 *__restrict__ xy1, int n0_pad, int n1_pad, int tiles_per_wg,

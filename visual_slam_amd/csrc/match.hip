@@ -262,9 +262,9 @@ static_assert(kDotLds <= 160 * 1024, "the ring and the transposition areas fit t
 // One workgroup = one band: kBM rows of desc0 of one frame pair against `tiles_per_wg` consecutive
 // kBN-column tiles of desc1.  4 waves, each a 64 x 64 sub-tile as 2 x 2 MFMA 32x32x16 f16 tiles.
 // Every wave keeps the fp16 fragments of its 64 desc0 rows (all 256 k) in registers for the whole
-// band; desc1 streams through a two-stage LDS ring, one barrier per K-step, the DMA of the next
-// K-step (also across tile boundaries) in flight behind the MFMAs and the epilogue of the current
-// one.  Epilogue: per-column top-2 over the wave's 64 rows (in registers) and per-row top-2 over
+// band; desc1 streams through a kRing-stage LDS ring, one barrier per K-step, the DMAs of the next
+// kRing - 1 K-steps (also across tile boundaries) in flight behind the MFMAs and the epilogue of
+// the current one.  Epilogue: per-column top-2 over the wave's 64 rows (in registers) and per-row top-2 over
 // its 64 columns (transposed through a wave-private LDS area, no barrier).
 #ifdef VS_MATCH_STAMPS      // timeline instrumentation build: cycle stamps of one workgroup's first tiles
 __device__ unsigned long long g_match_stamps[4 * 64];

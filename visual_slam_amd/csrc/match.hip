@@ -248,7 +248,10 @@ constexpr int kRowsPerDma = 64 / kChunksPerRow;         // image rows per DMA wa
 constexpr int kRowsPerWave = kBN / 4;                   // image rows one wave fills per stage
 constexpr int kDmaPerWave = kRowsPerWave / kRowsPerDma; // DMA instructions per wave and stage
 constexpr int kSwzShift = kBK == 128 ? 0 : (kBK == 64 ? 1 : 2);   // log2(rows per 256-byte bank line)
-constexpr int kInflight = (kRing - 2) * kDmaPerWave;    // DMAs allowed in flight behind stage s
+// DMAs allowed in flight behind stage s when it is read: with four stages one stage less than the
+// ring would allow, i.e. stage s + 1 has landed too -- a K-step of margin between the counter
+// saying so and the first read (see the note on stale pieces at kRing)
+constexpr int kInflight = (kRing >= 4 ? kRing - 3 : kRing - 2) * kDmaPerWave;
 static_assert(kBK == 32 || kBK == 64 || kBK == 128, "swizzle is written for 64-, 128- and 256-byte image rows");
 __device__ __forceinline__ int stage_swizzle(int row) { return (row >> kSwzShift) & (kChunksPerRow - 1); }
 constexpr int kTS = 68;                                 // transpose row stride in floats

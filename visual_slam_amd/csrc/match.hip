@@ -44,15 +44,9 @@ constexpr int kBM = 64 * kWR, kBN = 64 * kWC;      // workgroup tile
 #endif
 constexpr int kBK = VS_BK;             // halfs per K-step (one ring stage)
 #ifndef VS_RING
-#define VS_RING 4
+#define VS_RING 2
 #endif
-// Four stages (64 KB) + the transposition areas = 98 KB: ONE workgroup per CU, one wave per SIMD.
-// The earlier shape (two stages, two workgroups per CU, 0.57 ms per 64-pair batch against 0.76 ms
-// now) returned a few wrong nearest neighbours per 4096 x 4096 pair whenever a grid put more than
-// four waves on a CU: rarely a 1 KiB LDS-DMA piece was read before it had landed although its wave
-// had waited for vmcnt(0) and the workgroup had passed the barrier (tools/match_stress3.py counts
-// them against the exact CPU argmin; a three-stage ring failed the same way even alone on a CU,
-// a delay after the barrier made the errors rarer).  This shape ran that stress clean.
+// Two stages (32 KB) + the transposition areas = 66 KB: two workgroups per CU, two waves per SIMD.
 constexpr int kRing = VS_RING;         // LDS ring stages (kRing - 1 K-steps of lookahead)
 constexpr int kSub = 64;               // rows/cols covered by one wave = granularity of partials
 constexpr float kScale = 256.0f;       // descriptor prescale (2^8), dot prescale 2^16
@@ -248,10 +242,8 @@ constexpr int kRowsPerDma = 64 / kChunksPerRow;         // image rows per DMA wa
 constexpr int kRowsPerWave = kBN / 4;                   // image rows one wave fills per stage
 constexpr int kDmaPerWave = kRowsPerWave / kRowsPerDma; // DMA instructions per wave and stage
 constexpr int kSwzShift = kBK == 128 ? 0 : (kBK == 64 ? 1 : 2);   // log2(rows per 256-byte bank line)
-// DMAs allowed in flight behind stage s when it is read: with four stages one stage less than the
-// ring would allow, i.e. stage s + 1 has landed too -- a K-step of margin between the counter
-// saying so and the first read (see the note on stale pieces at kRing)
-constexpr int kInflight = (kRing >= 4 ? kRing - 3 : kRing - 2) * kDmaPerWave;
+// DMAs allowed in flight behind stage s when it is read: those of the kRing - 2 younger stages
+constexpr int kInflight = (kRing - 2) * kDmaPerWave;
 static_assert(kBK == 32 || kBK == 64 || kBK == 128, "swizzle is written for 64-, 128- and 256-byte image rows");
 __device__ __forceinline__ int stage_swizzle(int row) { return (row >> kSwzShift) & (kChunksPerRow - 1); }
 constexpr int kTS = 68;                                 // transpose row stride in floats
@@ -400,11 +392,17 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         // queue, which exposes one LDS latency per sub-step.
         const unsigned lbase = (unsigned)(uintptr_t)(smem) + (unsigned)((s % kRing) * kStageBytes + frag_row);
         half8 bf[3][2];
+        // The outputs are early-clobber: without it the compiler may give the address the first
+        // register of an output, and the second read then takes its address from a register the
+        // first read (still in flight) is about to overwrite -- harmless while the second read
+        // issues within the first one's latency, a garbage address (out-of-range LDS reads return
+        // zero: 8 of a column's 256 products lost) when the wave is held up between the two.
+#define VS_FRAG_OUT(x) "=&v"(x)
 #define VS_FRAG_READS(set, ks_)                                                               \
         do {                                                                                  \
             const unsigned a_ = lbase + (unsigned)((((2 * (ks_) + half) ^ swz) * 16));        \
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"               \
-                         : "=v"(bf[set][0]), "=v"(bf[set][1]) : "v"(a_), "n"(32 * kBK * 2) : "memory"); \
+                         : VS_FRAG_OUT(bf[set][0]), VS_FRAG_OUT(bf[set][1]) : "v"(a_), "n"(32 * kBK * 2) : "memory"); \
         } while (0)
         VS_FRAG_READS(0, 0);
         VS_FRAG_READS(1, 1);

@@ -91,3 +91,45 @@ def test_c5_windows_match_oracle_and_shards_add_up(orc, c5):
         tot_S += Sp; tot_rhs += rp; tot_cost += cp
         part.close()
     assert rel(tot_S, S) < 1e-12 and rel(tot_rhs, rhs) < 1e-12 and abs(tot_cost - cost) < 1e-12 * cost
+
+
+def damped_system_residual(sc, gpu, dcam):
+    """|S d - rhs| / |rhs| of the damped block-sparse reduced system the handle holds after an LM step."""
+    import scipy.sparse as sp
+    br, bc, Sd, rhs_d, _ = gpu.reduced_system()
+    n = 6 * sc.Nc
+    off = br != bc
+    rows = np.concatenate([br, bc[off]]); cols = np.concatenate([bc, br[off]])
+    data = np.concatenate([Sd, Sd[off].transpose(0, 2, 1)])
+    order = np.lexsort((cols, rows))
+    indptr = np.searchsorted(rows[order], np.arange(sc.Nc + 1))
+    A = sp.bsr_matrix((data[order], cols[order], indptr), shape=(n, n))
+    return np.linalg.norm(A @ dcam.ravel() - rhs_d) / np.linalg.norm(rhs_d)
+
+
+def test_c5_lm_step_solves_its_reduced_system(c5):
+    """The LM step of the full 10k-camera problem (block cyclic reduction over 192-wide blocks,
+    nine levels): the camera step satisfies the damped reduced system it was computed from, the
+    model cost decreases, the landmark steps are finite."""
+    sc = c5
+    gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    dcam, dpt, mcc = gpu.lm_step(1e4)
+    assert damped_system_residual(sc, gpu, dcam) < 1e-9
+    assert mcc > 0 and np.isfinite(dpt).all() and np.isfinite(dcam).all()
+    # the step moves every landmark (none left at zero by a skipped tile)
+    assert (np.abs(dpt).max(axis=1) > 0).mean() > 0.999
+    gpu.close()
+
+
+def test_cyclic_reduction_matches_band_cholesky_at_10k_cameras(monkeypatch):
+    """10k cameras, 50k landmarks, band of 32: cyclic reduction (nine levels) against the sequential
+    band Cholesky on the same handle, and both against the reduced system."""
+    sc = synth.make_ba_scene(10_000, 50_000, 5, band=32, seed=41)
+    gpu = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    d1, p1, m1 = gpu.lm_step(1e4)
+    assert damped_system_residual(sc, gpu, d1) < 1e-9
+    monkeypatch.setenv("VS_BA_SOLVER", "band")
+    d2, p2, m2 = gpu.lm_step(1e4)
+    monkeypatch.delenv("VS_BA_SOLVER")
+    assert rel(d1, d2) < 1e-8 and rel(p1, p2) < 1e-8 and abs(m1 - m2) < 1e-9 * abs(m2)
+    gpu.close()

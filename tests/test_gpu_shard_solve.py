@@ -142,3 +142,33 @@ def test_native_communicator_with_one_rank():
     _lib.check(lib.vs_ba_set_comm(b.h, None))
     b.close()
     _lib.check(lib.vs_comm_destroy(comm))
+
+
+def test_sharded_handles_give_the_same_answers_when_used_twice():
+    """A second solve on the same shard handles (after a first one has run its candidate-cost
+    passes) starts from the same initial cost and takes the same iterates as the unsharded handle:
+    the cost partials of a candidate evaluation must not leak into the next linearisation.  The
+    scene has enough landmarks for rank 1's first landmark tile to lie beyond index 0."""
+    import torch
+    sc = synth.make_ba_scene(12, 3000, 4, band=6, seed=21)
+    whole = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    ar = TwoRankAllReduce(torch)
+    parts = [BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=r, world=2)
+             for r in range(2)]
+    for r in range(2):
+        parts[r].set_allreduce(ar.hook(r))
+    for round_ in range(2):
+        whole.set_cameras(sc.t0, sc.rpy0); whole.set_points(sc.pts0)
+        for r in range(2):
+            parts[r].set_cameras(sc.t0, sc.rpy0); parts[r].set_points(sc.pts0)
+        ref = whole.solve(max_num_iterations=4)
+        outs = run_two_ranks(lambda r: parts[r].solve(max_num_iterations=4))
+        for r in range(2):
+            o = outs[r]
+            assert abs(o["initial_cost"] - ref["initial_cost"]) < 1e-12 * ref["initial_cost"], (round_, r)
+            assert o["iterations"] == ref["iterations"] and o["successful_steps"] == ref["successful_steps"]
+            assert abs(o["final_cost"] - ref["final_cost"]) < 1e-9 * ref["final_cost"]
+    # a shard with no way to sum refuses to step on its own part
+    lone = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=1, world=2)
+    with pytest.raises(Exception):
+        lone.lm_step(1e4)

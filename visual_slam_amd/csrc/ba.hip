@@ -124,6 +124,10 @@ struct vs_ba {
     DevBuf<BlockItem> items, diag_items;
     DevBuf<unsigned char> cam_used, pt_used;
     DevBuf<real> luv, cuv, lmrec, Vdiag, hub_w, cost_partial, diag_partial, off_partial, red;
+    // cost_kernel's partials (one per 256 landmarks): a buffer of their own, because the landmark
+    // kernels' partials (one per tile of kLmPerBlock landmarks, only a shard's own tiles rewritten)
+    // are summed over the whole of cost_partial by the block and finalize kernels
+    DevBuf<real> ccost_partial;
     DevBuf<real> scale_c, scale_p, lam_c, lam_c_user, lam_p_user, dcam, dpt, mcc_partial,
         cand_partial, gmax_partial, scalars, dense, linv, bcr_ws;
     DevBuf<int> info;
@@ -557,6 +561,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
     VS_HIP(hipMemsetAsync(h->cost_partial.p, 0, (size_t)std::max(h->n_lm4_blocks, 1) * sizeof(real), s));
     if (h->lmrec.p) VS_HIP(hipMemsetAsync(h->lmrec.p, 0, h->lmrec.n * sizeof(real), s));
     if (h->Vdiag.p) VS_HIP(hipMemsetAsync(h->Vdiag.p, 0, h->Vdiag.n * sizeof(real), s));
+    VS_TRY(h->ccost_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
     VS_TRY(h->mcc_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
     h->red_len = (int64_t)Nc * 36 + (int64_t)nb_off * 36 + 18 * (int64_t)Nc + 1;
     VS_TRY(h->red.alloc((size_t)h->red_len));
@@ -692,6 +697,16 @@ int cross_gpu_sum(vs_ba *h, real *buf, int64_t n)
 
 bool is_sharded(const vs_ba *h) { return h->world > 1 && (h->comm || h->allreduce); }
 
+// A shard of a multi-GPU problem cannot take an LM step on its own: its reduced system is a
+// partial sum.
+int ensure_sum_path(const vs_ba *h)
+{
+    VS_CHECK(h->world == 1 || h->comm || h->allreduce, VS_ERR_STATE,
+             "shard %d of %d has neither a communicator (vs_ba_set_comm) nor an all-reduce callback (vs_ba_set_allreduce)",
+             h->rank, h->world);
+    return VS_OK;
+}
+
 // Maximum over the shards of the double at device pointer `val` (in place).  The callback form
 // only sums: every rank writes its value into its own slot of a zeroed array, the array is summed
 // and the maximum of the slots is taken.
@@ -819,18 +834,18 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         if (h->stage_cams)   // few cameras: the workgroups build the candidate's camera records themselves
             hipLaunchKernelGGL(cost_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
                                (const CamData *)nullptr, h->t2.p, h->rpy2.p, (CamData *)nullptr, h->pts2.p, h->pt_ptr.p,
-                               h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+                               h->lcam.p, h->luv.p, h->hub, h->ccost_partial.p);
         else {
             VS_TRY(prep_cameras(h, h->t2.p, h->rpy2.p));
             hipLaunchKernelGGL(cost_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, Np, Nc, h->K,
                                h->cams.p, (const real *)nullptr, (const real *)nullptr, (CamData *)nullptr, h->pts2.p,
-                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->ccost_partial.p);
         }
         VS_TRY(launch_check("cost_kernel"));
     }
     // model cost change, |x|^2, |d|^2, candidate cost and the solver status: one launch, one copy
     hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->mcc_partial.p, ncb,
-                       h->cand_partial.p, want_candidate_cost ? h->n_lm_blocks : 0, h->cost_partial.p, h->info.p,
+                       h->cand_partial.p, want_candidate_cost ? h->n_lm_blocks : 0, h->ccost_partial.p, h->info.p,
                        h->scalars.p);
     VS_TRY(launch_check("step_scalars_kernel"));
     real *host8 = h->host_scalars.p;
@@ -956,6 +971,9 @@ int vs_ba_set_observations_sharded(vs_ba_handle h, const int32_t *cam, const int
     VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
     VS_CHECK(h->No_global == 0 || (cam && pt && uv), VS_ERR_INVALID, "null observation arrays");
     VS_CHECK(world >= 1 && rank >= 0 && rank < world, VS_ERR_INVALID, "bad shard %d of %d", rank, world);
+    VS_CHECK(h->comm == nullptr || (comm_rank(h->comm) == rank && comm_world(h->comm) == world), VS_ERR_INVALID,
+             "shard %d of %d does not match the attached communicator (rank %d of %d)", rank, world,
+             comm_rank(h->comm), comm_world(h->comm));
     h->rank = rank; h->world = world;
     return build_structure(h, cam, pt, uv);
 }
@@ -1005,13 +1023,13 @@ int vs_ba_evaluate(vs_ba_handle h, double *cost, double *res, double *Jc, double
         if (h->stage_cams)
             hipLaunchKernelGGL(cost_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, h->Np, h->Nc, h->K,
                                h->cams.p, (const real *)nullptr, (const real *)nullptr, (CamData *)nullptr, h->pts.p,
-                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->ccost_partial.p);
         else
             hipLaunchKernelGGL(cost_kernel<false>, dim3(h->n_lm_blocks), dim3(kLmThreads), 0, s, h->Np, h->Nc, h->K,
                                h->cams.p, (const real *)nullptr, (const real *)nullptr, (CamData *)nullptr, h->pts.p,
-                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->cost_partial.p);
+                               h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->ccost_partial.p);
         VS_TRY(launch_check("cost_kernel"));
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->cost_partial.p, h->scalars.p + 5);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, h->n_lm_blocks, h->ccost_partial.p, h->scalars.p + 5);
         VS_HIP(hipMemcpyAsync(cost, h->scalars.p + 5, sizeof(real), hipMemcpyDefault, s));
     }
     if (res) VS_HIP(hipMemcpyAsync(res, dres.p, 2 * (size_t)Ng * sizeof(real), hipMemcpyDefault, s));
@@ -1170,6 +1188,7 @@ int vs_ba_set_comm(vs_ba_handle h, vs_comm_handle c)
 int vs_ba_lm_step(vs_ba_handle h, double radius, double *dcam, double *dpt, double *mcc)
 {
     VS_TRY(ensure_state(h));
+    VS_TRY(ensure_sum_path(h));
     VS_CHECK(radius > 0.0, VS_ERR_INVALID, "radius must be positive");
     vs_lm_options o;
     vs_lm_default_options(&o);
@@ -1192,6 +1211,7 @@ int vs_ba_lm_step(vs_ba_handle h, double radius, double *dcam, double *dpt, doub
 int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summary)
 {
     VS_TRY(ensure_state(h));
+    VS_TRY(ensure_sum_path(h));
     vs_lm_options o;
     if (opts) o = *opts; else vs_lm_default_options(&o);
     hipStream_t s = h->stream;

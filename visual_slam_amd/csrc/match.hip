@@ -1493,14 +1493,22 @@ __global__ void noalloc_setup_kernel(PairDims *dims, unsigned *stats, int n0, in
     if (threadIdx.x < 4) stats[threadIdx.x] = 0u;
 }
 
+// Pointers a thread has already shown to be device memory are not asked about again: a serving
+// loop or a graph capture that reuses its buffers then makes no runtime query per call.
 int device_pointer_check(const void *p, const char *what)
 {
+    constexpr int kKnown = 8;
+    static thread_local const void *known[kKnown] = {};
+    static thread_local int next = 0;
+    for (int i = 0; i < kKnown; i++)
+        if (known[i] == p) return VS_OK;
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeUnregistered) {
         (void)hipGetLastError();
         set_error("%s must be a device pointer", what);
         return VS_ERR_INVALID;
     }
+    known[next] = p; next = (next + 1) % kKnown;
     return VS_OK;
 }
 }  // namespace
@@ -1523,6 +1531,9 @@ int vs_match_two_way_noalloc(const float *desc0, int32_t n0, const float *desc1,
     VS_TRY(device_pointer_check(desc0, "desc0")); VS_TRY(device_pointer_check(desc1, "desc1"));
     VS_TRY(device_pointer_check(out_i, "out_i")); VS_TRY(device_pointer_check(out_j, "out_j"));
     VS_TRY(device_pointer_check(out_d, "out_d"));
+    // the descriptors are read in place as 16-byte vectors
+    VS_CHECK(((uintptr_t)desc0 & 15) == 0 && ((uintptr_t)desc1 & 15) == 0, VS_ERR_INVALID,
+             "descriptor arrays must be 16-byte aligned");
     int dev = 0;
     VS_HIP(hipGetDevice(&dev));
     VS_CHECK(dev >= 0 && dev < kMaxDevices, VS_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev, kMaxDevices);

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VS_DOT
 dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b16,
                 const PairDims *__restrict__ dims, const int2 *__restrict__ xy0,
                 const int2 *__restrict__ xy1, int n0_pad, int n1_pad, int tiles_per_wg,
-                float2 *__restrict__ row_part, float2 *__restrict__ col_part)
+                float2 *__restrict__ row_part, float2 *__restrict__ col_part, float4 *__restrict__ row_sum)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kDotLds];
 
@@ -358,6 +358,12 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
 #pragma unroll
     for (int st = 0; st < kRing - 1; st++)
         if (st < n_stages) VS_ISSUE_STAGE(st);
+    // Running (best, second) of this lane's row over the tiles of the band, with the 64-column
+    // chunk the best lies in: after a tile's row pass every lane holds the finished pair of ONE
+    // row, so the band's union costs a handful of instructions per tile, and the merge kernel
+    // reads one summary per row and band instead of one partial per row and tile.
+    float band_b1 = kNegInf, band_b2 = kNegInf;
+    int band_chunk = c_begin;
     for (int tc = c_begin; tc < c_end; tc++) {
     const int j0 = tc * kBN;
     VS_STAMP();
@@ -551,12 +557,17 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         top2_union(b1, b2, __uint_as_float(s1[1]), __uint_as_float(s2[1]));
         const int64_t o = ((int64_t)pair * (n1_pad / kSub) + (j0 / kSub + wc)) * n0_pad + i0 + wr * 64 + half * 32 + l31;
         row_part[o] = make_float2(b1, b2);
+        if (b1 > band_b1) band_chunk = j0 / kSub + wc;     // strictly greater: the first chunk wins ties, as in the merge
+        top2_union(band_b1, band_b2, b1, b2);
         const int64_t oc = ((int64_t)pair * (n0_pad / kSub) + (i0 / kSub + wr)) * n1_pad + j0 + wc * 64 + half * 32 + l31;
         col_part[oc] = col_out;
     }
     __builtin_amdgcn_sched_barrier(0);
     VS_STAMP();
     }   // column tiles of the band
+    if (row_sum)
+        row_sum[((int64_t)pair * splits + split) * n0_pad + i0 + wr * 64 + half * 32 + l31] =
+            make_float4(band_b1, band_b2, __int_as_float(band_chunk), 0.f);
 #ifdef VS_MATCH_STAMPS
     if (stamp_on && lane == 0)
         for (int i = 0; i < 64; i++) g_match_stamps[wave * 64 + i] = i < n_stamp ? s_stamps[wave * 64 + i] : 0ull;
@@ -624,14 +635,24 @@ merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
              const float2 *__restrict__ row_part, const float2 *__restrict__ col_part,
              const unsigned *__restrict__ stats, int *__restrict__ idx0, int *__restrict__ idx1,
              int *__restrict__ rescan_list, int *__restrict__ rescan_count, int want_second,
-             int *__restrict__ sec_idx, int *__restrict__ sec_list)
+             int *__restrict__ sec_idx, int *__restrict__ sec_list,
+             const float4 *__restrict__ row_sum, int splits, int tiles_per_band)
 {
+    // Items that need an exact pass are listed through two counters in global memory.  A single
+    // word takes about 90 atomic adds per microsecond, and a 64-pair batch lists some ten thousand
+    // items: the workgroup counts its items in LDS and draws its range with one add per list.
+    __shared__ int wg_n[2], wg_base[2];
+    if (threadIdx.x < 2) wg_n[threadIdx.x] = 0;
+    __syncthreads();
     const int pair = blockIdx.y;
     const int it = blockIdx.x * 256 + threadIdx.x;
-    if (it >= n0_pad + n1_pad) return;
     const PairDims d = dims[pair];
+    bool list_item = false, list_second = false;
+    int my_slot = 0, my_slot2 = 0, self = 0;
+    if (it < n0_pad + n1_pad) {
     const ItemView v = item_view(pair, it, d, n0_pad, n1_pad, row_part, col_part);
-    if (v.self >= (v.is_row ? d.n0 : d.n1)) return;
+    self = v.self;
+    if (v.self < (v.is_row ? d.n0 : d.n1)) {
     float b1 = kNegInf, b2 = kNegInf;
     int pbest = 0;
     const int parts = (v.n_cand + kSub - 1) / kSub;
@@ -640,6 +661,16 @@ merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
 #pragma unroll
     for (int k = 0; k < 3; k++) { t3.v[k] = kNegInf; t3.tag[k] = -1; }
     int p = 0;
+    if (v.is_row && row_sum && !second) {
+        // rows: the score kernel has already united the partials of each band (same order, same
+        // tie rule), one summary per band
+        for (int sp = 0; sp < splits && sp * tiles_per_band * kBN < d.n1; sp++) {   // bands beyond the pair's columns did not run
+            const float4 q = row_sum[((int64_t)pair * splits + sp) * n0_pad + v.self];
+            if (q.x > b1) pbest = __float_as_int(q.z);
+            top2_union(b1, b2, q.x, q.y);
+        }
+        p = parts;
+    }
     for (; p + 8 <= parts; p += 8) {                  // eight loads in flight per thread
         float2 q[8];
 #pragma unroll
@@ -662,20 +693,27 @@ merge_kernel(const PairDims *__restrict__ dims, int n0_pad, int n1_pad,
     else idx1[(int64_t)pair * n1_pad + v.self] = win;
     const float band = pair_band(stats, pair);
     const bool uncertain = !(clamp_score(b1) - clamp_score(b2) > band);
-    if (uncertain && parts > 0) {
-        const int slot = atomicAdd(rescan_count, 1);
-        rescan_list[2 * (int64_t)slot] = pair;
-        rescan_list[2 * (int64_t)slot + 1] = it;
-    }
+    if (uncertain && parts > 0) { list_item = true; my_slot = atomicAdd(&wg_n[0], 1); }
     if (second) {
         const bool plain = !uncertain && (t3.tag[1] & 1) && (t3.tag[1] >> 1) != (t3.tag[0] >> 1) &&
                            clamp_score(t3.v[1]) - clamp_score(t3.v[2]) > band;
         sec_idx[(int64_t)pair * n0_pad + v.self] = plain ? partial_index(true, t3.tag[1] >> 1, t3.v[1]) : -1;
-        if (!plain) {
-            const int slot = atomicAdd(rescan_count + 1, 1);
-            sec_list[2 * (int64_t)slot] = pair;
-            sec_list[2 * (int64_t)slot + 1] = v.self;
-        }
+        if (!plain) { list_second = true; my_slot2 = atomicAdd(&wg_n[1], 1); }
+    }
+    }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && wg_n[threadIdx.x] > 0) wg_base[threadIdx.x] = atomicAdd(rescan_count + threadIdx.x, wg_n[threadIdx.x]);
+    __syncthreads();
+    if (list_item) {
+        const int64_t slot = wg_base[0] + my_slot;
+        rescan_list[2 * slot] = pair;
+        rescan_list[2 * slot + 1] = it;
+    }
+    if (list_second) {
+        const int64_t slot = wg_base[1] + my_slot2;
+        sec_list[2 * slot] = pair;
+        sec_list[2 * slot + 1] = self;
     }
 }
 
@@ -1037,6 +1075,7 @@ struct vs_matcher {
     DevBuf<int2> xy0, xy1;
     DevBuf<PairDims> dims;
     DevBuf<float2> row_part, col_part;   // (best, second) packed scores per item and 64-chunk
+    DevBuf<float4> row_sum;              // band summaries of the rows (see dot_top2_kernel)
     DevBuf<float> dist0, dist1, second0, out_d;
     DevBuf<int> idx0, idx1, rescan_list, rescan_count, out_i, out_j, out_n;
     DevBuf<int> sec_idx, sec_list;      // ratio test: second-best column per row, rows that need the exact scan
@@ -1072,6 +1111,7 @@ int vs_matcher_create(vs_matcher_handle *out, int32_t max_pairs, int32_t max_n0,
     A(m->split_part.alloc(P * 2 * (size_t)m->part_blocks * 2));
     const size_t rp = P * (r1 / kSub) * r0, cp = P * (r0 / kSub) * r1;
     A(m->row_part.alloc(rp)); A(m->col_part.alloc(cp));
+    A(m->row_sum.alloc(P * r0 * (size_t)std::max<size_t>(1, (r1 / kBN) / 4)));   // bands of >= 4 tiles
     A(m->idx0.alloc(P * r0)); A(m->idx1.alloc(P * r1)); A(m->dist0.alloc(P * r0)); A(m->dist1.alloc(P * r1));
     A(m->second0.alloc(P * r0)); A(m->sec_idx.alloc(P * r0)); A(m->sec_list.alloc(2 * P * r0));
     A(m->rescan_list.alloc(2 * P * (r0 + r1))); A(m->rescan_count.alloc(4));
@@ -1191,6 +1231,8 @@ struct MatchView {
     const int2 *xy0, *xy1;           // keypoints (stereo mask) or unused
     PairDims *dims;
     float2 *row_part, *col_part;     // (best, second) packed scores per item and 64-chunk
+    float4 *row_sum = nullptr;       // per row and band of the score kernel: (best, second, chunk of the best) or null
+    size_t row_sum_len = 0;          // float4 elements available at row_sum
     float *dist0, *dist1, *second0;
     int *idx0, *idx1, *rescan_list, *rescan_count;   // rescan_count: [0] uncertain items, [1] rows for the exact second-best scan
     int *sec_idx, *sec_list;
@@ -1222,19 +1264,23 @@ static int run_match(const MatchView &v, int n_pairs, bool masked, float nn_thre
     const int splits = div_up(ntc, tiles_per_wg);
     mark(0);
     const dim3 grid(n_pairs * ntr * splits);
+    // band summaries of the rows: worth their 16 bytes per row and band when a band unites at least
+    // four tiles (the merge then reads them instead of the per-tile partials)
+    float4 *row_sum = nullptr;
+    if (v.row_sum && tiles_per_wg >= 4 && (size_t)n_pairs * splits * r0 <= v.row_sum_len) row_sum = v.row_sum;
     if (masked)
         hipLaunchKernelGGL(dot_top2_kernel<true>, grid, dim3(256), 0, s, v.a16, v.b16, v.dims, v.xy0,
-                           v.xy1, r0, r1, tiles_per_wg, v.row_part, v.col_part);
+                           v.xy1, r0, r1, tiles_per_wg, v.row_part, v.col_part, row_sum);
     else
         hipLaunchKernelGGL(dot_top2_kernel<false>, grid, dim3(256), 0, s, v.a16, v.b16, v.dims, v.xy0,
-                           v.xy1, r0, r1, tiles_per_wg, v.row_part, v.col_part);
+                           v.xy1, r0, r1, tiles_per_wg, v.row_part, v.col_part, row_sum);
     VS_TRY(launch_ok("dot_top2_kernel"));
     mark(1);
     const int want_second = ratio < 1.0f ? 1 : 0;     // the ratio test needs the exact second-smallest distance of the output rows
     VS_HIP(hipMemsetAsync(v.rescan_count, 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(merge_kernel, dim3(div_up(r0 + r1, 256), n_pairs), dim3(256), 0, s, v.dims, r0, r1,
                        v.row_part, v.col_part, v.stats, v.idx0, v.idx1, v.rescan_list,
-                       v.rescan_count, want_second, v.sec_idx, v.sec_list);
+                       v.rescan_count, want_second, v.sec_idx, v.sec_list, row_sum, splits, tiles_per_wg);
     VS_TRY(launch_ok("merge_kernel"));
     mark(2);
     if (masked)
@@ -1301,6 +1347,7 @@ static MatchView handle_view(vs_matcher *m)
     v.d0 = m->d0.p; v.d1 = m->d1.p; v.a16 = m->a16.p; v.b16 = m->b16.p; v.stats = m->stats.p;
     v.xy0 = m->xy0.p; v.xy1 = m->xy1.p; v.dims = m->dims.p;
     v.row_part = m->row_part.p; v.col_part = m->col_part.p;
+    v.row_sum = m->row_sum.p; v.row_sum_len = m->row_sum.n;
     v.dist0 = m->dist0.p; v.dist1 = m->dist1.p; v.second0 = m->second0.p;
     v.idx0 = m->idx0.p; v.idx1 = m->idx1.p; v.rescan_list = m->rescan_list.p; v.rescan_count = m->rescan_count.p;
     v.sec_idx = m->sec_idx.p; v.sec_list = m->sec_list.p;

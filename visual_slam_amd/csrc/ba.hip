@@ -108,6 +108,8 @@ struct vs_ba {
     DevBuf<int> new2old;
     DevBuf<real> pts_user, perm_stage;
     DevBuf<real> rank_slots;    // one value per rank: maxima through a sum-only collective
+    DevBuf<unsigned char> arena;             // small edge sets: every index array in one block (build_structure)
+    PinnedBuf<unsigned char> arena_stage;
 
     std::vector<int32_t> h_brow, h_bcol;
     hipEvent_t *prof_ev = nullptr;   // when set: 6 events recorded around linearize()'s kernels
@@ -533,28 +535,57 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
 
     lap("work items");
     hipStream_t s = h->stream;
-    VS_TRY(h->pt_ptr.upload(pt_ptr.data(), pt_ptr.size(), s));
-    VS_TRY(h->lcam.upload(lcam.data(), lcam.size(), s));
-    VS_TRY(h->lpt.upload(lpt.data(), lpt.size(), s));
-    VS_TRY(h->lobs.upload(lobs.data(), lobs.size(), s));
-    VS_TRY(h->luv.upload(luv.data(), luv.size(), s));
-    VS_TRY(h->cam_ptr.upload(cam_ptr.data(), cam_ptr.size(), s));
-    VS_TRY(h->cpt.upload(cpt.data(), cpt.size(), s));
-    VS_TRY(h->cuv.upload(cuv.data(), cuv.size(), s));
-    VS_TRY(h->cam_used.upload(cam_used.data(), cam_used.size(), s));
-    VS_TRY(h->pt_used.upload(pt_used.data(), pt_used.size(), s));
     std::vector<int> one(1, 0);
-    VS_TRY(h->brow.upload(nb_off ? h->h_brow.data() : one.data(), std::max(nb_off, 1), s));
-    VS_TRY(h->bcol.upload(nb_off ? h->h_bcol.data() : one.data(), std::max(nb_off, 1), s));
-    VS_TRY(h->bent.upload(bent.data(), bent.size(), s));
-    auto up = [&](DevBuf<int> &d, std::vector<int> &v) { if (v.empty()) v.push_back(0); return d.upload(v.data(), v.size(), s); };
-    VS_TRY(up(h->ditem_ptr, di_ptr)); VS_TRY(up(h->oitem_ptr, oi_ptr));
     if (items.empty()) items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
     if (diag_items.empty()) diag_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
     if (small_items.empty()) small_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
-    VS_TRY(h->small_items.upload(small_items.data(), small_items.size(), s));
-    VS_TRY(h->items.upload(items.data(), items.size(), s));
-    VS_TRY(h->diag_items.upload(diag_items.data(), diag_items.size(), s));
+    if (di_ptr.empty()) di_ptr.push_back(0);
+    if (oi_ptr.empty()) oi_ptr.push_back(0);
+    // The index arrays go to the device as ONE copy when they are small (the reference's own
+    // window sizes): they are packed into a page-locked staging block and the handle's buffers
+    // become windows of one device arena.  Twenty separate copies from pageable memory cost more
+    // than building the arrays.  Large edge sets are copied array by array, straight from the vectors.
+    struct Part { void *view_buf; int kind; const void *src; size_t bytes, count, off; };
+    std::vector<Part> parts;
+    size_t total = 0;
+    auto add = [&](void *buf, int kind, const void *src, size_t count, size_t elem) {
+        parts.push_back(Part{ buf, kind, src, count * elem, count, total });
+        total += (count * elem + 255) / 256 * 256;
+    };
+    add(&h->pt_ptr, 0, pt_ptr.data(), pt_ptr.size(), sizeof(int));
+    add(&h->lcam, 0, lcam.data(), lcam.size(), sizeof(int));
+    add(&h->lpt, 0, lpt.data(), lpt.size(), sizeof(int));
+    add(&h->lobs, 0, lobs.data(), lobs.size(), sizeof(int));
+    add(&h->luv, 1, luv.data(), luv.size(), sizeof(real));
+    add(&h->cam_ptr, 0, cam_ptr.data(), cam_ptr.size(), sizeof(int));
+    add(&h->cpt, 0, cpt.data(), cpt.size(), sizeof(int));
+    add(&h->cuv, 1, cuv.data(), cuv.size(), sizeof(real));
+    add(&h->cam_used, 2, cam_used.data(), cam_used.size(), 1);
+    add(&h->pt_used, 2, pt_used.data(), pt_used.size(), 1);
+    add(&h->brow, 0, nb_off ? h->h_brow.data() : one.data(), (size_t)std::max(nb_off, 1), sizeof(int));
+    add(&h->bcol, 0, nb_off ? h->h_bcol.data() : one.data(), (size_t)std::max(nb_off, 1), sizeof(int));
+    add(&h->bent, 0, bent.data(), bent.size(), sizeof(int));
+    add(&h->ditem_ptr, 0, di_ptr.data(), di_ptr.size(), sizeof(int));
+    add(&h->oitem_ptr, 0, oi_ptr.data(), oi_ptr.size(), sizeof(int));
+    add(&h->small_items, 3, small_items.data(), small_items.size(), sizeof(BlockItem));
+    add(&h->items, 3, items.data(), items.size(), sizeof(BlockItem));
+    add(&h->diag_items, 3, diag_items.data(), diag_items.size(), sizeof(BlockItem));
+    const bool packed = total <= ((size_t)2 << 20);
+    if (packed) {
+        if (h->arena.n < total || !h->arena.p) VS_TRY(h->arena.alloc(total));
+        if (h->arena_stage.n < total) VS_TRY(h->arena_stage.alloc(total));
+        for (const Part &q : parts) memcpy(h->arena_stage.p + q.off, q.src, q.bytes);
+        VS_HIP(hipMemcpyAsync(h->arena.p, h->arena_stage.p, total, hipMemcpyHostToDevice, s));
+    }
+    for (const Part &q : parts) {
+        unsigned char *at = packed ? h->arena.p + q.off : nullptr;
+        switch (q.kind) {
+        case 0: { auto *b = (DevBuf<int> *)q.view_buf; if (packed) b->view((int *)at, q.count); else { if (b->is_view) b->release(); VS_TRY(b->upload((const int *)q.src, q.count, s)); } break; }
+        case 1: { auto *b = (DevBuf<real> *)q.view_buf; if (packed) b->view((real *)at, q.count); else { if (b->is_view) b->release(); VS_TRY(b->upload((const real *)q.src, q.count, s)); } break; }
+        case 2: { auto *b = (DevBuf<unsigned char> *)q.view_buf; if (packed) b->view(at, q.count); else { if (b->is_view) b->release(); VS_TRY(b->upload((const unsigned char *)q.src, q.count, s)); } break; }
+        default: { auto *b = (DevBuf<BlockItem> *)q.view_buf; if (packed) b->view((BlockItem *)at, q.count); else { if (b->is_view) b->release(); VS_TRY(b->upload((const BlockItem *)q.src, q.count, s)); } break; }
+        }
+    }
     VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
     VS_TRY(h->off_partial.alloc((size_t)std::max(h->n_off_items, 1) * kOffVals));
     VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm4_blocks, 1)));

@@ -35,31 +35,50 @@ void set_error(const char *fmt, ...);
         if (s_ != VS_OK) return s_;                                                             \
     } while (0)
 
-// Owning device buffer; freed on destruction or reset.
+// Blocks from the process-wide pool (capi.hip): device memory, or page-locked host memory.  A block
+// belongs to the device that was current at pool_alloc (*device; -1: not pooled); `bytes` and
+// `device` at pool_free are those of pool_alloc.
+void *pool_alloc(size_t bytes, bool host, int *status, int *device);
+void pool_free(void *p, size_t bytes, bool host, int device);
+
+// Owning device buffer; returned to the pool on destruction or reset.  The owner makes sure no
+// work that uses the buffer is still running when it lets go of it: handles synchronise their
+// stream before they are destroyed, and growing a live buffer waits for the device first.
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    int dev = -1;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { reset(); }
-    void reset()
+    ~DevBuf() { release(); }
+    bool is_view = false;    // points into another buffer (see view()): nothing to give back
+    void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !is_view) pool_free(p, n * sizeof(T), false, dev);
         p = nullptr;
         n = 0;
+        is_view = false;
+    }
+    // Non-owning window of `count` elements at `ptr` (part of an arena that outlives this buffer).
+    void view(T *ptr, size_t count)
+    {
+        release();
+        p = ptr; n = count; is_view = true;
+    }
+    void reset()
+    {
+        if (p && !is_view) (void)hipDeviceSynchronize();     // hipFree would have waited as well
+        release();
     }
     int alloc(size_t count)
     {
         reset();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-            return e == hipErrorOutOfMemory ? VS_ERR_NOMEM : VS_ERR_HIP;
-        }
+        int rc = VS_OK;
+        p = (T *)pool_alloc(count * sizeof(T), false, &rc, &dev);
+        if (rc != VS_OK) { p = nullptr; return rc; }
         n = count;
         return VS_OK;
     }
@@ -76,20 +95,20 @@ struct DevBuf {
 template <typename T>
 struct PinnedBuf {
     T *p = nullptr;
+    size_t n = 0;
+    int dev = -1;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
     PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    ~PinnedBuf() { if (p) pool_free(p, n * sizeof(T), true, dev); }
     int alloc(size_t count)
     {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        hipError_t e = hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-            return VS_ERR_NOMEM;
-        }
+        if (p) pool_free(p, n * sizeof(T), true, dev);
+        p = nullptr; n = 0;
+        int rc = VS_OK;
+        p = (T *)pool_alloc(count * sizeof(T), true, &rc, &dev);
+        if (rc != VS_OK) { p = nullptr; return rc; }
+        n = count;
         return VS_OK;
     }
 };

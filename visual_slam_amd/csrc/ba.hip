@@ -110,6 +110,11 @@ struct vs_ba {
     DevBuf<real> rank_slots;    // one value per rank: maxima through a sum-only collective
     DevBuf<unsigned char> arena;             // small edge sets: every index array in one block (build_structure)
     PinnedBuf<unsigned char> arena_stage;
+    // Small parameter uploads pass through page-locked staging owned by the handle, so the setters
+    // need not wait for the copy: [t | rpy | points].  busy[r]: a copy out of region r may still be
+    // in flight (r = 0 cameras, 1 points, 2 the arena staging).
+    PinnedBuf<real> param_stage;
+    bool busy[3] = { false, false, false };
 
     std::vector<int32_t> h_brow, h_bcol;
     hipEvent_t *prof_ev = nullptr;   // when set: 6 events recorded around linearize()'s kernels
@@ -570,12 +575,22 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
     add(&h->small_items, 3, small_items.data(), small_items.size(), sizeof(BlockItem));
     add(&h->items, 3, items.data(), items.size(), sizeof(BlockItem));
     add(&h->diag_items, 3, diag_items.data(), diag_items.size(), sizeof(BlockItem));
+    const size_t one_off = total;      // a double 1.0 for the Huber weight rides along
+    total += 256;
     const bool packed = total <= ((size_t)2 << 20);
     if (packed) {
+        if (h->busy[2]) {      // the staging block of an earlier edge set may still be on its way
+            VS_HIP(hipStreamSynchronize(s));
+            h->busy[0] = h->busy[1] = h->busy[2] = false;
+        }
         if (h->arena.n < total || !h->arena.p) VS_TRY(h->arena.alloc(total));
         if (h->arena_stage.n < total) VS_TRY(h->arena_stage.alloc(total));
         for (const Part &q : parts) memcpy(h->arena_stage.p + q.off, q.src, q.bytes);
+        const real one_r = 1.0;
+        memcpy(h->arena_stage.p + one_off, &one_r, sizeof(real));
         VS_HIP(hipMemcpyAsync(h->arena.p, h->arena_stage.p, total, hipMemcpyHostToDevice, s));
+        VS_HIP(hipMemcpyAsync(h->hub_w.p, h->arena_stage.p + one_off, sizeof(real), hipMemcpyHostToDevice, s));
+        h->busy[2] = true;
     }
     for (const Part &q : parts) {
         unsigned char *at = packed ? h->arena.p + q.off : nullptr;
@@ -597,9 +612,14 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
     h->red_len = (int64_t)Nc * 36 + (int64_t)nb_off * 36 + 18 * (int64_t)Nc + 1;
     VS_TRY(h->red.alloc((size_t)h->red_len));
     VS_HIP(hipMemsetAsync(h->red.p, 0, (size_t)h->red_len * sizeof(real), s));
-    const real one_r = 1.0;
-    VS_HIP(hipMemcpyAsync(h->hub_w.p, &one_r, sizeof(real), hipMemcpyHostToDevice, s));
-    VS_HIP(hipStreamSynchronize(s));
+    // Everything a packed edge set sent came out of the handle's own staging; otherwise the copies
+    // read vectors that die with this call.
+    if (!(packed && h->stage_cams)) {
+        const real one_r = 1.0;
+        VS_HIP(hipMemcpyAsync(h->hub_w.p, &one_r, sizeof(real), hipMemcpyHostToDevice, s));
+        VS_HIP(hipStreamSynchronize(s));
+        h->busy[0] = h->busy[1] = h->busy[2] = false;
+    }
     lap("allocations + uploads");
     h->have_obs = true;
     h->linearized = false;
@@ -972,12 +992,42 @@ int vs_ba_set_stream(vs_ba_handle h, void *stream)
     return VS_OK;
 }
 
+// Small host arrays are copied into the handle's page-locked staging and leave from there, so the
+// caller's array is free on return without waiting for the stream.
+static bool stageable(const vs_ba *h, const void *src)
+{
+    if ((6 * (size_t)h->Nc + 3 * (size_t)h->Np) * sizeof(real) > ((size_t)512 << 10)) return false;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess) return attr.type == hipMemoryTypeUnregistered;
+    (void)hipGetLastError();      // plain host memory is unknown to the runtime
+    return true;
+}
+static int claim_stage(vs_ba *h, int region)
+{
+    if (!h->param_stage.p) VS_TRY(h->param_stage.alloc(6 * (size_t)h->Nc + 3 * (size_t)h->Np));
+    if (h->busy[region]) {
+        VS_HIP(hipStreamSynchronize(h->stream));
+        h->busy[0] = h->busy[1] = h->busy[2] = false;
+    }
+    return VS_OK;
+}
+
 int vs_ba_set_cameras(vs_ba_handle h, const double *t, const double *rpy)
 {
     VS_CHECK(h && t && rpy, VS_ERR_INVALID, "null argument");
-    VS_HIP(hipMemcpyAsync(h->t.p, t, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
-    VS_HIP(hipMemcpyAsync(h->rpy.p, rpy, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
-    VS_HIP(hipStreamSynchronize(h->stream));
+    const size_t n = 3 * (size_t)h->Nc;
+    if (stageable(h, t) && stageable(h, rpy)) {
+        VS_TRY(claim_stage(h, 0));
+        memcpy(h->param_stage.p, t, n * sizeof(real));
+        memcpy(h->param_stage.p + n, rpy, n * sizeof(real));
+        VS_HIP(hipMemcpyAsync(h->t.p, h->param_stage.p, n * sizeof(real), hipMemcpyHostToDevice, h->stream));
+        VS_HIP(hipMemcpyAsync(h->rpy.p, h->param_stage.p + n, n * sizeof(real), hipMemcpyHostToDevice, h->stream));
+        h->busy[0] = true;
+    } else {
+        VS_HIP(hipMemcpyAsync(h->t.p, t, n * sizeof(real), hipMemcpyDefault, h->stream));
+        VS_HIP(hipMemcpyAsync(h->rpy.p, rpy, n * sizeof(real), hipMemcpyDefault, h->stream));
+        VS_HIP(hipStreamSynchronize(h->stream));
+    }
     h->have_cams = true; h->linearized = false; h->have_scale = false; h->prelin = false;
     return VS_OK;
 }
@@ -985,13 +1035,22 @@ int vs_ba_set_cameras(vs_ba_handle h, const double *t, const double *rpy)
 int vs_ba_set_points(vs_ba_handle h, const double *xyz)
 {
     VS_CHECK(h && xyz, VS_ERR_INVALID, "null argument");
+    const size_t n = 3 * (size_t)h->Np;
+    const bool staged = stageable(h, xyz);
+    const real *src = xyz;
+    if (staged) {
+        VS_TRY(claim_stage(h, 1));
+        memcpy(h->param_stage.p + 6 * (size_t)h->Nc, xyz, n * sizeof(real));
+        src = h->param_stage.p + 6 * (size_t)h->Nc;
+    }
     if (h->renum) {
-        VS_HIP(hipMemcpyAsync(h->pts_user.p, xyz, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+        VS_HIP(hipMemcpyAsync(h->pts_user.p, src, n * sizeof(real), hipMemcpyDefault, h->stream));
         VS_TRY(rows_to_internal(h, 3, h->pts_user.p, h->pts.p));
     } else {
-        VS_HIP(hipMemcpyAsync(h->pts.p, xyz, 3 * (size_t)h->Np * sizeof(real), hipMemcpyDefault, h->stream));
+        VS_HIP(hipMemcpyAsync(h->pts.p, src, n * sizeof(real), hipMemcpyDefault, h->stream));
     }
-    VS_HIP(hipStreamSynchronize(h->stream));
+    if (staged) h->busy[1] = true;
+    else VS_HIP(hipStreamSynchronize(h->stream));
     h->have_pts = true; h->linearized = false; h->have_scale = false; h->prelin = false;
     return VS_OK;
 }

@@ -12,6 +12,7 @@
 #include "ba_kernels.h"
 #include "dense_solve.h"
 #include "bcr_solve.h"
+#include "ba_build.h"
 
 using namespace vs;
 
@@ -214,6 +215,168 @@ int rows_to_caller(vs_ba *h, int width, const real *src, int src_stride, int src
     return launch_check("scatter_rows_kernel");
 }
 
+// Work-item lists of the block kernels from the camera-major and camera-pair entry counts
+// (cam_ptr: Nc + 1, bptr: nb_off + 1, both on the host); also the landmark-tile range of this shard.
+struct ItemLists {
+    std::vector<BlockItem> items, diag_items, small_items;
+    std::vector<int> di_ptr, oi_ptr;
+};
+int make_items(vs_ba *h, const int *cam_ptr, const int *bptr, ItemLists &out)
+{
+    const int Nc = h->Nc, Np = h->Np, nb_off = h->nb_off, No = h->No, pt_lo = h->pt_lo, pt_hi = h->pt_hi;
+    const int n_ent = bptr[nb_off];
+    // work items: one workgroup each; 4 waves per item and 4 entries per thread when the typical
+    // block is large, else 1 wave and 3 entries (measured optima at 50 / 1000 / 10000 cameras).  Blocks that fit one item are written by the block kernel directly,
+    // the others go through partials + finalize.
+    {
+        int64_t nb_used = 0, nc_used = 0;
+        for (int c = 0; c < Nc; c++) nc_used += cam_ptr[c + 1] > cam_ptr[c];
+        for (int k = 0; k < nb_off; k++) nb_used += bptr[k + 1] > bptr[k];
+        const double avg = nb_used ? double(n_ent) / double(nb_used) : (nc_used ? double(No) / double(nc_used) : 0.0);
+        h->item_waves = avg >= 512.0 ? 4 : 1;
+    }
+    if (const char *e = getenv("VS_BA_ITEM_WAVES")) h->item_waves = atoi(e) == 4 ? 4 : 1;   // tuning knobs
+    int ept = h->item_waves == 4 ? kEpt4 : kEpt1;          // entries per thread and item
+    if (const char *e = getenv("VS_BA_ITEM_EPT")) ept = std::min(ept, std::max(1, atoi(e)));
+    // a 4-wave item holds up to max_chunks chunks of entries (the block kernel walks them in a loop
+    // with the sums in registers): fewer partials, and at 50 cameras every block is one item
+    const int chunk = h->item_waves * kWave * ept;
+    const int max_chunks = h->item_waves == 4 ? 24 / kEpt4 : 1;   // 6144 entries per 4-wave item
+    const int ch = chunk * max_chunks;
+    // Items are listed block row by block row (camera c's diagonal item(s), then its
+    // off-diagonal blocks (c, c') in column order) so that a contiguous range of items is a band
+    // of cameras.  With fixed points only the diagonal items are launched (diag_items).
+    std::vector<BlockItem> &items = out.items, &diag_items = out.diag_items, &small_items = out.small_items;
+    std::vector<BlockItem> small32;
+    items.clear(); diag_items.clear(); small_items.clear();
+    // Off-diagonal blocks of at most 32 entries go to the small-block kernels (several blocks per
+    // wave) when they hold a tenth of all entries or more: otherwise two more launches cost more
+    // than the idle lanes of those blocks in the block kernel.
+    bool pack_small = h->item_waves == 1 && getenv("VS_BA_NO_SMALL_BLOCKS") == nullptr;
+    if (pack_small) {
+        int64_t small_entries = 0;
+        for (int k = 0; k < nb_off; k++) {
+            const int nk = bptr[k + 1] - bptr[k];
+            if (nk <= 32) small_entries += nk;
+        }
+        pack_small = small_entries * 10 >= (int64_t)n_ent;
+    }
+    std::vector<int> &di_ptr = out.di_ptr, &oi_ptr = out.oi_ptr;
+    di_ptr.assign((size_t)Nc + 1, 0); oi_ptr.assign((size_t)nb_off + 1, 0);
+    int n_diag_items = 0, n_off_items = 0;
+    {
+        int k = 0;   // off-diagonal blocks are sorted by (row, col): walk them row by row
+        for (int c = 0; c < Nc; c++) {
+            const size_t first = items.size();
+            for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += ch)
+                items.push_back(BlockItem{ c, b, std::min(b + ch, cam_ptr[c + 1]), c, c, 0, n_diag_items++, 0 });
+            di_ptr[c + 1] = n_diag_items;
+            if (items.size() - first == 1) items[first].single = 1;
+            for (size_t i = first; i < items.size(); i++) diag_items.push_back(items[i]);
+            for (; k < nb_off && h->h_brow[k] == c; k++) {
+                const int nk = bptr[k + 1] - bptr[k];
+                if (pack_small && nk >= 1 && nk <= 32) {   // four / two such blocks share a wave of the small-block kernel
+                    (nk <= 16 ? small_items : small32).push_back(BlockItem{ k, bptr[k], bptr[k + 1], h->h_brow[k], h->h_bcol[k], 1, n_off_items++, 0 });
+                    oi_ptr[k + 1] = n_off_items;
+                    continue;
+                }
+                const size_t f2 = items.size();
+                for (int b = bptr[k]; b < bptr[k + 1]; b += ch)
+                    items.push_back(BlockItem{ k, b, std::min(b + ch, bptr[k + 1]), h->h_brow[k], h->h_bcol[k], 0, n_off_items++, 0 });
+                oi_ptr[k + 1] = n_off_items;
+                if (items.size() - f2 == 1) items[f2].single = 1;
+            }
+        }
+        for (int kk = 0; kk < nb_off; kk++) oi_ptr[kk + 1] = std::max(oi_ptr[kk + 1], oi_ptr[kk]);
+    }
+    // The block kernel gives workgroups with equal blockIdx % 8 one contiguous eighth of the list
+    // and the hardware starts workgroups in blockIdx order: put each eighth's share of the
+    // (heavier) diagonal items at its front so that they never sit in the last round.  Only with
+    // the few large items of the 4-wave form: with many small items the last round is short anyway
+    // and keeping a camera's diagonal item next to its row of blocks is worth more (measured).
+    if (h->item_waves == 4 && !items.empty()) {
+        std::vector<BlockItem> dg, off;
+        for (const BlockItem &it : items) (it.ca == it.cb ? dg : off).push_back(it);
+        const size_t n = items.size(), q = n / 8, r = n % 8;
+        size_t id = 0, io = 0, pos = 0;
+        for (size_t x = 0; x < 8; x++) {
+            const size_t len = q + (x < r ? 1 : 0);
+            size_t nd = dg.size() / 8 + (x < dg.size() % 8 ? 1 : 0);
+            nd = std::min(nd, len);
+            // off-diagonal items left over when the diagonal share does not fit go to later eighths
+            for (size_t i = 0; i < nd; i++) items[pos++] = dg[id++];
+            for (size_t i = nd; i < len; i++) {
+                if (io < off.size()) items[pos++] = off[io++];
+                else items[pos++] = dg[id++];
+            }
+        }
+    }
+    h->n_diag_items = n_diag_items;
+    h->n_off_items = n_off_items;
+    h->n_list_items = (int)items.size();
+    h->n_small16 = (int)small_items.size();
+    h->n_small32 = (int)small32.size();
+    small_items.insert(small_items.end(), small32.begin(), small32.end());
+    h->n_multi_diag = h->n_multi_off = 0;          // blocks that are not exactly one item: finalize sums (or zeroes) them
+    for (int c = 0; c < Nc; c++) h->n_multi_diag += di_ptr[c + 1] - di_ptr[c] != 1;   // empty blocks too:
+    for (int k = 0; k < nb_off; k++) h->n_multi_off += oi_ptr[k + 1] - oi_ptr[k] != 1; // finalize zeroes them
+    h->n_lm_blocks = div_up(Np, kLmThreads);
+    h->n_lm4_blocks = div_up(Np, kLmPerBlock);
+    // a shard's landmark kernel runs over its own tiles only; the records and cost partials of the
+    // other tiles are zeroed once (below) and never written
+    h->tile_lo = h->world > 1 ? pt_lo / kLmPerBlock : 0;
+    h->tile_hi = h->world > 1 ? std::max(h->tile_lo + 1, div_up(pt_hi, kLmPerBlock)) : h->n_lm4_blocks;
+    h->tile_hi = std::min(h->tile_hi, std::max(h->n_lm4_blocks, 1));
+    if (h->tile_lo >= h->tile_hi) h->tile_lo = std::max(0, h->tile_hi - 1);
+
+    h->stage_cams = (size_t)Nc * (sizeof(CamData) + 6 * sizeof(real)) <= 48 * 1024;
+    if (items.empty()) items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
+    if (diag_items.empty()) diag_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
+    if (small_items.empty()) small_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
+    if (di_ptr.empty()) di_ptr.push_back(0);
+    if (oi_ptr.empty()) oi_ptr.push_back(0);
+    return VS_OK;
+}
+
+// The all-cameras-in-a-CU's-LDS form of the landmark kernel, where it applies (after make_items).
+int choose_lds_cameras(vs_ba *h)
+{
+    const int Nc = h->Nc;
+    // Up to about 1200 cameras every camera fits the LDS of a CU as one array (one persistent
+    // workgroup per CU, no separate camera pass): preferred over the range staging where both apply
+    // (config 4 in keyframe order: 31 us against 33 + 4 us for range staging and its camera pass)
+    h->lds_cam_grid = 0;
+    if (!h->stage_cams && (size_t)Nc * kCamLdsReals * sizeof(real) <= kLdsCamBytesMax &&
+        getenv("VS_BA_NO_LDS_CAMS") == nullptr) {
+        int dev = 0, cus = 0;
+        VS_HIP(hipGetDevice(&dev));
+        VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        VS_TRY(landmark_lds_raise_limit());
+        h->lds_cam_grid = std::max(1, std::min(cus, div_up(h->tile_hi - h->tile_lo, kLmBigThreads / kLmThreads)));
+    }
+
+    return VS_OK;
+}
+
+// Buffers whose size follows from the item lists, zeroed where kernels rely on it.
+int alloc_work_buffers(vs_ba *h)
+{
+    hipStream_t s = h->stream;
+    const int Nc = h->Nc, nb_off = h->nb_off;
+    VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
+    VS_TRY(h->off_partial.alloc((size_t)std::max(h->n_off_items, 1) * kOffVals));
+    VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm4_blocks, 1)));
+    VS_HIP(hipMemsetAsync(h->cost_partial.p, 0, (size_t)std::max(h->n_lm4_blocks, 1) * sizeof(real), s));
+    if (h->lmrec.p) VS_HIP(hipMemsetAsync(h->lmrec.p, 0, h->lmrec.n * sizeof(real), s));
+    if (h->Vdiag.p) VS_HIP(hipMemsetAsync(h->Vdiag.p, 0, h->Vdiag.n * sizeof(real), s));
+    VS_TRY(h->ccost_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
+    VS_TRY(h->mcc_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
+    h->red_len = (int64_t)Nc * 36 + (int64_t)nb_off * 36 + 18 * (int64_t)Nc + 1;
+    VS_TRY(h->red.alloc((size_t)h->red_len));
+    VS_HIP(hipMemsetAsync(h->red.p, 0, (size_t)h->red_len * sizeof(real), s));
+    return VS_OK;
+}
+
 // Builds every index structure from the caller's edge list (host side, once per edge set).
 int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const double *uv)
 {
@@ -404,107 +567,10 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         }
     }
     lap("camera-major view");
-    // work items: one workgroup each; 4 waves per item and 4 entries per thread when the typical
-    // block is large, else 1 wave and 3 entries (measured optima at 50 / 1000 / 10000 cameras).  Blocks that fit one item are written by the block kernel directly,
-    // the others go through partials + finalize.
-    {
-        int64_t nb_used = 0, nc_used = 0;
-        for (int c = 0; c < Nc; c++) nc_used += cam_ptr[c + 1] > cam_ptr[c];
-        for (int k = 0; k < nb_off; k++) nb_used += bptr[k + 1] > bptr[k];
-        const double avg = nb_used ? double(n_ent) / double(nb_used) : (nc_used ? double(No) / double(nc_used) : 0.0);
-        h->item_waves = avg >= 512.0 ? 4 : 1;
-    }
-    if (const char *e = getenv("VS_BA_ITEM_WAVES")) h->item_waves = atoi(e) == 4 ? 4 : 1;   // tuning knobs
-    int ept = h->item_waves == 4 ? kEpt4 : kEpt1;          // entries per thread and item
-    if (const char *e = getenv("VS_BA_ITEM_EPT")) ept = std::min(ept, std::max(1, atoi(e)));
-    // a 4-wave item holds up to max_chunks chunks of entries (the block kernel walks them in a loop
-    // with the sums in registers): fewer partials, and at 50 cameras every block is one item
-    const int chunk = h->item_waves * kWave * ept;
-    const int max_chunks = h->item_waves == 4 ? 24 / kEpt4 : 1;   // 6144 entries per 4-wave item
-    const int ch = chunk * max_chunks;
-    // Items are listed block row by block row (camera c's diagonal item(s), then its
-    // off-diagonal blocks (c, c') in column order) so that a contiguous range of items is a band
-    // of cameras.  With fixed points only the diagonal items are launched (diag_items).
-    std::vector<BlockItem> items, diag_items, small_items, small32;
-    // Off-diagonal blocks of at most 32 entries go to the small-block kernels (several blocks per
-    // wave) when they hold a tenth of all entries or more: otherwise two more launches cost more
-    // than the idle lanes of those blocks in the block kernel.
-    bool pack_small = h->item_waves == 1 && getenv("VS_BA_NO_SMALL_BLOCKS") == nullptr;
-    if (pack_small) {
-        int64_t small_entries = 0;
-        for (int k = 0; k < nb_off; k++) {
-            const int nk = bptr[k + 1] - bptr[k];
-            if (nk <= 32) small_entries += nk;
-        }
-        pack_small = small_entries * 10 >= (int64_t)n_ent;
-    }
-    std::vector<int> di_ptr((size_t)Nc + 1, 0), oi_ptr((size_t)nb_off + 1, 0);
-    int n_diag_items = 0, n_off_items = 0;
-    {
-        int k = 0;   // off-diagonal blocks are sorted by (row, col): walk them row by row
-        for (int c = 0; c < Nc; c++) {
-            const size_t first = items.size();
-            for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += ch)
-                items.push_back(BlockItem{ c, b, std::min(b + ch, cam_ptr[c + 1]), c, c, 0, n_diag_items++, 0 });
-            di_ptr[c + 1] = n_diag_items;
-            if (items.size() - first == 1) items[first].single = 1;
-            for (size_t i = first; i < items.size(); i++) diag_items.push_back(items[i]);
-            for (; k < nb_off && h->h_brow[k] == c; k++) {
-                const int nk = bptr[k + 1] - bptr[k];
-                if (pack_small && nk >= 1 && nk <= 32) {   // four / two such blocks share a wave of the small-block kernel
-                    (nk <= 16 ? small_items : small32).push_back(BlockItem{ k, bptr[k], bptr[k + 1], h->h_brow[k], h->h_bcol[k], 1, n_off_items++, 0 });
-                    oi_ptr[k + 1] = n_off_items;
-                    continue;
-                }
-                const size_t f2 = items.size();
-                for (int b = bptr[k]; b < bptr[k + 1]; b += ch)
-                    items.push_back(BlockItem{ k, b, std::min(b + ch, bptr[k + 1]), h->h_brow[k], h->h_bcol[k], 0, n_off_items++, 0 });
-                oi_ptr[k + 1] = n_off_items;
-                if (items.size() - f2 == 1) items[f2].single = 1;
-            }
-        }
-        for (int kk = 0; kk < nb_off; kk++) oi_ptr[kk + 1] = std::max(oi_ptr[kk + 1], oi_ptr[kk]);
-    }
-    // The block kernel gives workgroups with equal blockIdx % 8 one contiguous eighth of the list
-    // and the hardware starts workgroups in blockIdx order: put each eighth's share of the
-    // (heavier) diagonal items at its front so that they never sit in the last round.  Only with
-    // the few large items of the 4-wave form: with many small items the last round is short anyway
-    // and keeping a camera's diagonal item next to its row of blocks is worth more (measured).
-    if (h->item_waves == 4 && !items.empty()) {
-        std::vector<BlockItem> dg, off;
-        for (const BlockItem &it : items) (it.ca == it.cb ? dg : off).push_back(it);
-        const size_t n = items.size(), q = n / 8, r = n % 8;
-        size_t id = 0, io = 0, pos = 0;
-        for (size_t x = 0; x < 8; x++) {
-            const size_t len = q + (x < r ? 1 : 0);
-            size_t nd = dg.size() / 8 + (x < dg.size() % 8 ? 1 : 0);
-            nd = std::min(nd, len);
-            // off-diagonal items left over when the diagonal share does not fit go to later eighths
-            for (size_t i = 0; i < nd; i++) items[pos++] = dg[id++];
-            for (size_t i = nd; i < len; i++) {
-                if (io < off.size()) items[pos++] = off[io++];
-                else items[pos++] = dg[id++];
-            }
-        }
-    }
-    h->n_diag_items = n_diag_items;
-    h->n_off_items = n_off_items;
-    h->n_list_items = (int)items.size();
-    h->n_small16 = (int)small_items.size();
-    h->n_small32 = (int)small32.size();
-    small_items.insert(small_items.end(), small32.begin(), small32.end());
-    h->n_multi_diag = h->n_multi_off = 0;          // blocks that are not exactly one item: finalize sums (or zeroes) them
-    for (int c = 0; c < Nc; c++) h->n_multi_diag += di_ptr[c + 1] - di_ptr[c] != 1;   // empty blocks too:
-    for (int k = 0; k < nb_off; k++) h->n_multi_off += oi_ptr[k + 1] - oi_ptr[k] != 1; // finalize zeroes them
-    h->n_lm_blocks = div_up(Np, kLmThreads);
-    h->n_lm4_blocks = div_up(Np, kLmPerBlock);
-    // a shard's landmark kernel runs over its own tiles only; the records and cost partials of the
-    // other tiles are zeroed once (below) and never written
-    h->tile_lo = h->world > 1 ? pt_lo / kLmPerBlock : 0;
-    h->tile_hi = h->world > 1 ? std::max(h->tile_lo + 1, div_up(pt_hi, kLmPerBlock)) : h->n_lm4_blocks;
-    h->tile_hi = std::min(h->tile_hi, std::max(h->n_lm4_blocks, 1));
-    if (h->tile_lo >= h->tile_hi) h->tile_lo = std::max(0, h->tile_hi - 1);
-    h->stage_cams = (size_t)Nc * (sizeof(CamData) + 6 * sizeof(real)) <= 48 * 1024;
+    ItemLists lists;
+    VS_TRY(make_items(h, cam_ptr.data(), bptr.data(), lists));
+    std::vector<BlockItem> &items = lists.items, &diag_items = lists.diag_items, &small_items = lists.small_items;
+    std::vector<int> &di_ptr = lists.di_ptr, &oi_ptr = lists.oi_ptr;
     // More cameras than fit LDS: when the cameras seen by the landmarks of one landmark-kernel
     // workgroup span a short index range (keyframes in time order), that range is staged instead.
     h->lm_cam_span = 0;
@@ -525,27 +591,11 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         }
     }
 
-    // Up to about 1200 cameras every camera fits the LDS of a CU as one array (one persistent
-    // workgroup per CU, no separate camera pass): preferred over the range staging where both apply
-    // (config 4 in keyframe order: 31 us against 33 + 4 us for range staging and its camera pass)
-    h->lds_cam_grid = 0;
-    if (!h->stage_cams && (size_t)Nc * kCamLdsReals * sizeof(real) <= kLdsCamBytesMax &&
-        getenv("VS_BA_NO_LDS_CAMS") == nullptr) {
-        int dev = 0, cus = 0;
-        VS_HIP(hipGetDevice(&dev));
-        VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        VS_TRY(landmark_lds_raise_limit());
-        h->lds_cam_grid = std::max(1, std::min(cus, div_up(h->tile_hi - h->tile_lo, kLmBigThreads / kLmThreads)));
-    }
+    VS_TRY(choose_lds_cameras(h));
 
     lap("work items");
     hipStream_t s = h->stream;
     std::vector<int> one(1, 0);
-    if (items.empty()) items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
-    if (diag_items.empty()) diag_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
-    if (small_items.empty()) small_items.push_back(BlockItem{ 0, 0, 0, 0, 0, 0, 0, 0 });
-    if (di_ptr.empty()) di_ptr.push_back(0);
-    if (oi_ptr.empty()) oi_ptr.push_back(0);
     // The index arrays go to the device as ONE copy when they are small (the reference's own
     // window sizes): they are packed into a page-locked staging block and the handle's buffers
     // become windows of one device arena.  Twenty separate copies from pageable memory cost more
@@ -601,17 +651,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         default: { auto *b = (DevBuf<BlockItem> *)q.view_buf; if (packed) b->view((BlockItem *)at, q.count); else { if (b->is_view) b->release(); VS_TRY(b->upload((const BlockItem *)q.src, q.count, s)); } break; }
         }
     }
-    VS_TRY(h->diag_partial.alloc((size_t)std::max(h->n_diag_items, 1) * kDiagVals));
-    VS_TRY(h->off_partial.alloc((size_t)std::max(h->n_off_items, 1) * kOffVals));
-    VS_TRY(h->cost_partial.alloc((size_t)std::max(h->n_lm4_blocks, 1)));
-    VS_HIP(hipMemsetAsync(h->cost_partial.p, 0, (size_t)std::max(h->n_lm4_blocks, 1) * sizeof(real), s));
-    if (h->lmrec.p) VS_HIP(hipMemsetAsync(h->lmrec.p, 0, h->lmrec.n * sizeof(real), s));
-    if (h->Vdiag.p) VS_HIP(hipMemsetAsync(h->Vdiag.p, 0, h->Vdiag.n * sizeof(real), s));
-    VS_TRY(h->ccost_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
-    VS_TRY(h->mcc_partial.alloc((size_t)std::max(h->n_lm_blocks, 1)));
-    h->red_len = (int64_t)Nc * 36 + (int64_t)nb_off * 36 + 18 * (int64_t)Nc + 1;
-    VS_TRY(h->red.alloc((size_t)h->red_len));
-    VS_HIP(hipMemsetAsync(h->red.p, 0, (size_t)h->red_len * sizeof(real), s));
+    VS_TRY(alloc_work_buffers(h));
     // Everything a packed edge set sent came out of the handle's own staging; otherwise the copies
     // read vectors that die with this call.
     if (!(packed && h->stage_cams)) {
@@ -621,6 +661,190 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         h->busy[0] = h->busy[1] = h->busy[2] = false;
     }
     lap("allocations + uploads");
+    h->have_obs = true;
+    h->linearized = false;
+    h->have_scale = false; h->prelin = false;
+    return VS_OK;
+}
+
+// The same structures as build_structure, built on the device (ba_build.h): the edge list is
+// uploaded once, sorted by (landmark, camera) and by camera, the camera pairs are enumerated,
+// sorted and run-length encoded there; the host reads back the scalars, the per-camera and
+// per-pair counts and the pair list, cuts the work items and uploads them.
+int build_structure_device(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const double *uv)
+{
+    using namespace build;
+    const int Nc = h->Nc, Np = h->Np;
+    VS_CHECK(h->No_global < ((int64_t)1 << 31), VS_ERR_UNSUPPORTED, "more than 2^31 observations");
+    const int Ng = (int)h->No_global;
+    hipStream_t s = h->stream;
+    h->have_obs = false;
+    h->linearized = false;
+    const bool timing = getenv("VS_BA_BUILD_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "build_structure_device: %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    // points held in the internal order of an earlier edge set go back to the caller's order first
+    if (h->renum && h->have_pts) {
+        VS_TRY(rows_to_caller(h, 3, h->pts.p, 3, 0, h->pts_user.p));
+        VS_HIP(hipMemcpyAsync(h->pts.p, h->pts_user.p, 3 * (size_t)Np * sizeof(real), hipMemcpyDeviceToDevice, s));
+    }
+    h->renum = false;
+    auto grid = [](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + 255) / 256)); };
+    DevBuf<int> d_cam, d_pt, first_cam, first_sorted, iota, old2new, ovals, gord, gptr, npairs, poff;
+    DevBuf<real> d_uv;
+    DevBuf<unsigned long long> okeys_in, okeys;
+    DevBuf<unsigned char> tmp;
+    DevBuf<Scalars> sc;
+    PinnedBuf<Scalars> hsc;
+    VS_TRY(d_cam.upload(cam, Ng, s)); VS_TRY(d_pt.upload(pt_user, Ng, s)); VS_TRY(d_uv.upload(uv, 2 * (size_t)Ng, s));
+    VS_TRY(sc.alloc(1)); VS_TRY(hsc.alloc(1));
+    VS_TRY(first_cam.alloc(Np)); VS_TRY(first_sorted.alloc(Np)); VS_TRY(old2new.alloc(Np));
+    VS_TRY(iota.alloc((size_t)std::max(Np, Ng)));
+    VS_TRY(h->cam_used.alloc(Nc)); VS_TRY(h->pt_used.alloc(Np));
+    VS_HIP(hipMemsetAsync(h->cam_used.p, 0, (size_t)Nc, s));
+    VS_HIP(hipMemsetAsync(h->pt_used.p, 0, (size_t)Np, s));
+    lap("upload");
+    hipLaunchKernelGGL(init_kernel, grid(Np), dim3(256), 0, s, sc.p, Np, Nc, first_cam.p);
+    hipLaunchKernelGGL(first_cam_kernel, grid(Ng), dim3(256), 0, s, Ng, Nc, Np, d_cam.p, d_pt.p, first_cam.p, h->cam_used.p, sc.p);
+    hipLaunchKernelGGL(sorted_check_kernel, grid(Np), dim3(256), 0, s, Np, first_cam.p, sc.p);
+    // internal landmark numbering: a stable sort by first camera (the identity when already sorted)
+    const bool no_renum = getenv("VS_BA_NO_RENUMBER") != nullptr;
+    if (h->new2old.n < (size_t)Np || !h->new2old.p) VS_TRY(h->new2old.alloc(Np));
+    hipLaunchKernelGGL(iota_kernel, grid(Np), dim3(256), 0, s, Np, iota.p);
+    VS_TRY(sort_pairs(tmp, (const unsigned *)first_cam.p, (unsigned *)first_sorted.p, iota.p, h->new2old.p, Np, bits_for((long long)Nc + 1), s));
+    hipLaunchKernelGGL(invert_kernel, grid(Np), dim3(256), 0, s, Np, h->new2old.p, old2new.p, (int)no_renum);
+    // observations sorted by (landmark, camera)
+    VS_TRY(okeys_in.alloc(Ng)); VS_TRY(okeys.alloc(Ng)); VS_TRY(ovals.alloc(Ng)); VS_TRY(gord.alloc(Ng));
+    hipLaunchKernelGGL(obs_key_kernel, grid(Ng), dim3(256), 0, s, Ng, Nc, Np, d_cam.p, d_pt.p, old2new.p, okeys_in.p, ovals.p, h->pt_used.p);
+    VS_TRY(sort_pairs(tmp, okeys_in.p, okeys.p, ovals.p, gord.p, Ng, 32 + bits_for(Np), s));
+    hipLaunchKernelGGL(dup_check_kernel, grid(Ng), dim3(256), 0, s, Ng, okeys.p, sc.p);
+    VS_TRY(gptr.alloc((size_t)Np + 1)); VS_TRY(npairs.alloc(Np)); VS_TRY(poff.alloc(Np));
+    hipLaunchKernelGGL(landmark_ptr_kernel, grid((int64_t)Np + 1), dim3(256), 0, s, Ng, Np, okeys.p, gptr.p);
+    hipLaunchKernelGGL(shard_bounds_kernel, dim3(1), dim3(64), 0, s, Ng, Np, h->rank, h->world, gptr.p, sc.p);
+    hipLaunchKernelGGL(pair_count_kernel, grid(Np), dim3(256), 0, s, Np, gptr.p, npairs.p);
+    VS_TRY(exclusive_sum(tmp, npairs.p, poff.p, Np, s));
+    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, s, Np, poff.p, npairs.p, &sc.p->n_pairs);
+    VS_TRY(launch_check("structure kernels (observations)"));
+    VS_HIP(hipMemcpyAsync(hsc.p, sc.p, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    lap("observation sort");
+    {
+        const Scalars &q = *hsc.p;
+        VS_CHECK(q.bad_cam == INT_MAX, VS_ERR_INVALID, "observation %d: camera index %d out of range [0,%d)", q.bad_cam, cam[q.bad_cam], Nc);
+        VS_CHECK(q.bad_pt == INT_MAX, VS_ERR_INVALID, "observation %d: point index %d out of range [0,%d)", q.bad_pt, pt_user[q.bad_pt], Np);
+        if (q.dup != INT_MAX) {
+            unsigned long long key = 0;
+            VS_HIP(hipMemcpy(&key, okeys.p + q.dup, sizeof(key), hipMemcpyDeviceToHost));
+            int jn = (int)(key >> 32), ju = jn;
+            if (!no_renum) VS_HIP(hipMemcpy(&ju, h->new2old.p + jn, sizeof(int), hipMemcpyDeviceToHost));
+            set_error("point %d is observed twice by camera %d", ju, (int)(unsigned)(key & 0xffffffffull));
+            return VS_ERR_INVALID;
+        }
+        VS_CHECK(q.n_pairs >= 0, VS_ERR_UNSUPPORTED, "more than 2^31 camera-pair entries on one GPU");
+    }
+    const bool renum = !hsc.p->sorted && !no_renum;
+    if (renum) {
+        if (h->pts_user.n < 3 * (size_t)Np) VS_TRY(h->pts_user.alloc(3 * (size_t)std::max(Np, 1)));
+        if (h->perm_stage.n < 9 * (size_t)Np) VS_TRY(h->perm_stage.alloc(9 * (size_t)std::max(Np, 1)));
+        h->renum = true;
+        if (h->have_pts) {   // the points were set before the edges: bring them into the internal order
+            VS_HIP(hipMemcpyAsync(h->pts_user.p, h->pts.p, 3 * (size_t)Np * sizeof(real), hipMemcpyDeviceToDevice, s));
+            VS_TRY(rows_to_internal(h, 3, h->pts_user.p, h->pts.p));
+        }
+    }
+    const int pt_lo = hsc.p->pt_lo, pt_hi = hsc.p->pt_hi, lo_pos = hsc.p->lo_pos;
+    const int No = hsc.p->hi_pos - hsc.p->lo_pos, P = hsc.p->n_pairs;
+    h->pt_lo = pt_lo; h->pt_hi = pt_hi; h->No = No;
+    const size_t no1 = (size_t)std::max(No, 1);
+    VS_TRY(h->pt_ptr.alloc((size_t)Np + 1)); VS_TRY(h->lcam.alloc(no1)); VS_TRY(h->lpt.alloc(no1)); VS_TRY(h->lobs.alloc(no1));
+    VS_TRY(h->luv.alloc(2 * no1)); VS_TRY(h->cam_ptr.alloc((size_t)Nc + 1)); VS_TRY(h->cpt.alloc(no1)); VS_TRY(h->cuv.alloc(2 * no1));
+    hipLaunchKernelGGL(local_obs_kernel, grid(No), dim3(256), 0, s, No, lo_pos, okeys.p, gord.p, d_uv.p, h->lcam.p, h->lpt.p,
+                       h->lobs.p, h->luv.p, (int)(h->huber_a > 0.0), sc.p);
+    hipLaunchKernelGGL(local_ptr_kernel, grid((int64_t)Np + 1), dim3(256), 0, s, Np, No, lo_pos, gptr.p, h->pt_ptr.p);
+    // camera-major view: a stable sort of the landmark-major positions by camera
+    DevBuf<int> cpos;
+    DevBuf<unsigned> ccam;
+    VS_TRY(cpos.alloc(no1)); VS_TRY(ccam.alloc(no1));
+    if (No > 0) {
+        hipLaunchKernelGGL(iota_kernel, grid(No), dim3(256), 0, s, No, iota.p);
+        VS_TRY(sort_pairs(tmp, (const unsigned *)h->lcam.p, ccam.p, iota.p, cpos.p, No, bits_for(Nc), s));
+        hipLaunchKernelGGL(camera_major_kernel, grid(No), dim3(256), 0, s, No, cpos.p, h->lpt.p, h->luv.p, h->cpt.p, h->cuv.p);
+    }
+    hipLaunchKernelGGL(camera_ptr_kernel, grid((int64_t)Nc + 1), dim3(256), 0, s, No, Nc, ccam.p, h->cam_ptr.p);
+    // camera pairs of every landmark (the global pattern), sorted by (row, column); stable, so the
+    // landmarks of a pair stay ascending
+    DevBuf<unsigned long long> pkeys_in, pkeys;
+    DevBuf<int> pvals_in, pvals, head, loc, bidx, lsum, bptr_dev;
+    if (P > 0) {
+        VS_TRY(pkeys_in.alloc(P)); VS_TRY(pkeys.alloc(P)); VS_TRY(pvals_in.alloc(P)); VS_TRY(pvals.alloc(P));
+        VS_TRY(head.alloc(P)); VS_TRY(loc.alloc(P)); VS_TRY(bidx.alloc(P)); VS_TRY(lsum.alloc(P));
+        hipLaunchKernelGGL(pair_gen_kernel, grid(Np), dim3(256), 0, s, Np, gptr.p, poff.p, okeys.p, pkeys_in.p, pvals_in.p);
+        VS_TRY(sort_pairs(tmp, pkeys_in.p, pkeys.p, pvals_in.p, pvals.p, P, 32 + bits_for(Nc), s));
+        hipLaunchKernelGGL(pair_flags_kernel, grid(P), dim3(256), 0, s, P, pkeys.p, pvals.p, pt_lo, pt_hi, head.p, loc.p);
+        VS_TRY(exclusive_sum(tmp, head.p, bidx.p, P, s));
+        VS_TRY(exclusive_sum(tmp, loc.p, lsum.p, P, s));
+        hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, s, P, bidx.p, head.p, &sc.p->nb_off);
+        hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, s, P, lsum.p, loc.p, &sc.p->n_ent);
+    }
+    VS_TRY(launch_check("structure kernels (pairs)"));
+    VS_HIP(hipMemcpyAsync(hsc.p, sc.p, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    lap("views + pair sort");
+    const int nb_off = P > 0 ? hsc.p->nb_off : 0, n_ent = P > 0 ? hsc.p->n_ent : 0;
+    h->nb_off = nb_off;
+    VS_TRY(h->brow.alloc((size_t)std::max(nb_off, 1))); VS_TRY(h->bcol.alloc((size_t)std::max(nb_off, 1)));
+    VS_TRY(bptr_dev.alloc((size_t)nb_off + 1)); VS_TRY(h->bent.alloc((size_t)std::max(n_ent, 1)));
+    VS_HIP(hipMemsetAsync(h->brow.p, 0, sizeof(int) * (size_t)std::max(nb_off, 1), s));
+    VS_HIP(hipMemsetAsync(h->bcol.p, 0, sizeof(int) * (size_t)std::max(nb_off, 1), s));
+    VS_HIP(hipMemsetAsync(bptr_dev.p, 0, sizeof(int) * ((size_t)nb_off + 1), s));
+    if (P > 0)
+        hipLaunchKernelGGL(pair_scatter_kernel, grid(P), dim3(256), 0, s, P, pkeys.p, pvals.p, head.p, bidx.p, loc.p, lsum.p,
+                           h->brow.p, h->bcol.p, bptr_dev.p, h->bent.p);
+    VS_TRY(launch_check("pair_scatter_kernel"));
+    std::vector<int> cam_ptr((size_t)Nc + 1), bptr((size_t)nb_off + 1, 0);
+    h->h_brow.resize((size_t)nb_off); h->h_bcol.resize((size_t)nb_off);
+    VS_HIP(hipMemcpyAsync(cam_ptr.data(), h->cam_ptr.p, sizeof(int) * ((size_t)Nc + 1), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipMemcpyAsync(bptr.data(), bptr_dev.p, sizeof(int) * ((size_t)nb_off + 1), hipMemcpyDeviceToHost, s));
+    if (nb_off > 0) {
+        VS_HIP(hipMemcpyAsync(h->h_brow.data(), h->brow.p, sizeof(int) * (size_t)nb_off, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipMemcpyAsync(h->h_bcol.data(), h->bcol.p, sizeof(int) * (size_t)nb_off, hipMemcpyDeviceToHost, s));
+    }
+    VS_HIP(hipStreamSynchronize(s));
+    h->max_pair_gap = 0;
+    for (int b = 0; b < nb_off; b++) h->max_pair_gap = std::max(h->max_pair_gap, h->h_bcol[b] - h->h_brow[b]);
+    h->hub = HuberObs{ -1, -1, -1, (real)h->huber_a };
+    if (h->huber_a > 0.0 && hsc.p->hub_pos >= 0) { h->hub.pos = hsc.p->hub_pos; h->hub.cam = hsc.p->hub_cam; h->hub.pt = hsc.p->hub_pt; }
+    lap("blocks read back");
+    ItemLists lists;
+    VS_TRY(make_items(h, cam_ptr.data(), bptr.data(), lists));
+    h->lm_cam_span = 0;
+    if (!h->stage_cams && getenv("VS_BA_NO_RANGE_STAGING") == nullptr) {
+        VS_TRY(h->lm_cam_lo.alloc((size_t)std::max(h->n_lm4_blocks, 1)));
+        hipLaunchKernelGGL(tile_span_kernel, dim3(std::max(h->n_lm4_blocks, 1)), dim3(64), 0, s, h->n_lm4_blocks, Np, Nc, kLmPerBlock,
+                           h->pt_ptr.p, h->lcam.p, h->lm_cam_lo.p, sc.p);
+        VS_TRY(launch_check("tile_span_kernel"));
+        VS_HIP(hipMemcpyAsync(hsc.p, sc.p, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        if ((size_t)hsc.p->span * sizeof(CamData) <= 32 * 1024) h->lm_cam_span = hsc.p->span;
+    }
+    VS_TRY(choose_lds_cameras(h));
+    VS_TRY(h->ditem_ptr.upload(lists.di_ptr.data(), lists.di_ptr.size(), s));
+    VS_TRY(h->oitem_ptr.upload(lists.oi_ptr.data(), lists.oi_ptr.size(), s));
+    VS_TRY(h->small_items.upload(lists.small_items.data(), lists.small_items.size(), s));
+    VS_TRY(h->items.upload(lists.items.data(), lists.items.size(), s));
+    VS_TRY(h->diag_items.upload(lists.diag_items.data(), lists.diag_items.size(), s));
+    VS_TRY(alloc_work_buffers(h));
+    const real one_r = 1.0;
+    VS_HIP(hipMemcpyAsync(h->hub_w.p, &one_r, sizeof(real), hipMemcpyHostToDevice, s));
+    VS_HIP(hipStreamSynchronize(s));
+    h->busy[0] = h->busy[1] = h->busy[2] = false;
+    lap("items + buffers");
     h->have_obs = true;
     h->linearized = false;
     h->have_scale = false; h->prelin = false;
@@ -1065,7 +1289,11 @@ int vs_ba_set_observations_sharded(vs_ba_handle h, const int32_t *cam, const int
              "shard %d of %d does not match the attached communicator (rank %d of %d)", rank, world,
              comm_rank(h->comm), comm_world(h->comm));
     h->rank = rank; h->world = world;
-    return build_structure(h, cam, pt, uv);
+    // large edge sets are indexed on the device, small ones (a few launches' worth of work) on the
+    // host; VS_BA_BUILD=host|device forces one path (tests compare them)
+    bool on_device = h->No_global >= 32768;
+    if (const char *e = getenv("VS_BA_BUILD")) on_device = strcmp(e, "device") == 0 && h->No_global > 0;
+    return on_device ? build_structure_device(h, cam, pt, uv) : build_structure(h, cam, pt, uv);
 }
 
 int vs_ba_set_observations(vs_ba_handle h, const int32_t *cam, const int32_t *pt, const double *uv)

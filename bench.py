@@ -3,12 +3,13 @@
   python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5shard|c5]
 
 A step = one pass of the fused residual + Jacobian + Schur linearisation (vs_ba_linearize) over
-one synthetic bundle-adjustment problem resident in HBM, followed for N > 1 by the all-reduce of
-the reduced camera system.  The default workload is BASELINE.json configs[3] (1k cameras, 500k
+one synthetic bundle-adjustment problem resident in HBM, followed for N > 1 by the exchange that
+sums the ranks' partial reduced camera systems (vs_ba_exchange_reduced).  The default workload is BASELINE.json configs[3] (1k cameras, 500k
 landmarks, ~2M observations), the shape the metric's "1-8 GPU" part is quoted on: it fits one GPU
 and its landmarks shard over N GPUs, so every N runs the SAME problem (strong scaling): rank r
-linearises landmark shard r and the ranks sum their partial reduced systems with an RCCL
-all-reduce issued by the library on the step's own stream (vs_comm_allreduce_sum).
+linearises landmark shard r and sends the rows of the reduced system its landmarks touch; one
+RCCL all-gather issued by the library on the step's own stream moves them and every rank adds the
+pieces in rank order (the all-reduce of the whole buffer this replaced is timed beside it).
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (one process per
 GPU, before anything touches a GPU here); under torch.distributed.run the ranks are taken from the
 environment.  Rank 0 prints ONE JSON line; `value` is observations/s over all ranks.  The line
@@ -84,21 +85,50 @@ def bench_ba(args, rank, world, dist, torch, comm):
     sptr = C.c_void_p(stream.cuda_stream)
     trace("problem ready (%.1f s)" % setup_s)
 
-    def allreduce():
-        if comm is not None:      # RCCL all-reduce enqueued by the library on the step's stream
-            rc = lib.vs_comm_allreduce_sum(comm, C.c_void_p(ptr), C.c_int64(n), sptr)
-            assert rc == 0
-        elif dist is not None and dist.get_backend() == "nccl":
-            dist.all_reduce(red)  # the library's communicator did not come up: torch's RCCL group, same stream
-        elif dist is not None:    # rehearsal backend (gloo): summed on the host, copied back
-            host = red.cpu()
-            dist.all_reduce(host)
-            red.copy_(host)
+    # N > 1: the ranks combine their partial reduce buffers with vs_ba_exchange_reduced: every rank
+    # sends only the rows its landmarks touch (one all-gather, summed in rank order).  With the
+    # library's communicator the all-gather is RCCL on the step's stream; otherwise the gather and
+    # sum callbacks go through torch.distributed (rehearsal backends included).
+    if dist is not None:
+        if comm is not None:
+            assert lib.vs_ba_set_comm(ba.h, comm) == 0
+        else:
+            from visual_slam_amd import dist as vdist
+            if dist.get_backend() == "nccl":
+                vdist.attach_allgather(ba)
+                vdist.attach_allreduce(ba)
+            else:                   # rehearsal backend (gloo): through the host
+                def gather_host(send_ptr, recv_ptr, m):
+                    send = vdist.device_tensor(send_ptr, m).cpu()
+                    parts = [torch.empty_like(send) for _ in range(world)]
+                    dist.all_gather(parts, send)
+                    vdist.device_tensor(recv_ptr, m * world).copy_(torch.cat(parts))
+                    torch.cuda.synchronize()
+
+                def sum_host(buf_ptr, m):
+                    t = vdist.device_tensor(buf_ptr, m)
+                    host = t.cpu()
+                    dist.all_reduce(host)
+                    t.copy_(host)
+                    torch.cuda.synchronize()
+                ba.set_allgather(gather_host)
+                ba.set_allreduce(sum_host)
+
+    def exchange():
+        if dist is not None:
+            assert lib.vs_ba_exchange_reduced(ba.h) == 0
+
+    def exchange_whole_buffer():    # the all-reduce of the whole buffer this replaced, for comparison
+        os.environ["VS_BA_EXCHANGE"] = "allreduce"
+        try:
+            assert lib.vs_ba_exchange_reduced(ba.h) == 0
+        finally:
+            del os.environ["VS_BA_EXCHANGE"]
 
     def step():
         rc = lib.vs_ba_linearize(ba.h, pc, pp)
         assert rc == 0
-        allreduce()
+        exchange()
 
     def sync():
         if dist is not None:
@@ -123,14 +153,20 @@ def bench_ba(args, rank, world, dist, torch, comm):
     trace("warm-up done")
     dt = timed(step, args.steps)
     trace("timed region done")
-    allreduce_ms = None
+    allreduce_ms = exchange_ms = None
+    send_doubles = recv_doubles = 0
     if dist is not None:
-        allreduce_ms = timed(allreduce, max(10, args.steps // 10)) / max(10, args.steps // 10) * 1e3
+        reps = max(10, args.steps // 10)
+        exchange_ms = timed(exchange, reps) / reps * 1e3
+        allreduce_ms = timed(exchange_whole_buffer, reps) / reps * 1e3
+        send_doubles, recv_doubles = ba.exchange_size()
     ms_per_step = dt / args.steps * 1e3
     total_obs = sc.No
     value = total_obs / (dt / args.steps)
     out = dict(ms_per_step=ms_per_step, value=value, setup_s=setup_s, No=int(sc.No), Np=int(sc.Np),
-               Nc=int(sc.Nc), allreduce_ms_per_step=allreduce_ms, allreduce_bytes=int(n) * 8)
+               Nc=int(sc.Nc), allreduce_ms_per_step=allreduce_ms, allreduce_bytes=int(n) * 8,
+               exchange_ms_per_step=exchange_ms, exchange_send_bytes=int(send_doubles) * 8,
+               exchange_recv_bytes=int(recv_doubles) * 8)
     if rank == 0:
         ms = ba.profile_linearize(dc.cpu().numpy(), dp.cpu().numpy(), iters=max(20, args.steps // 2))
         br, _ = ba.block_index()
@@ -722,14 +758,15 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d cameras, %d landmarks, %d observations%s" % (
                 args.workload, ba["Nc"], ba["Np"], ba["No"],
-                "" if world == 1 else " (landmarks sharded over %d GPUs, RCCL all-reduce of the reduced camera system every step)" % world),
+                "" if world == 1 else " (landmarks sharded over %d GPUs, the reduced camera system combined every step: each rank all-gathers the rows its landmarks touch)" % world),
                 "precision": "fp64 values, int32 indices"},
             "roofline": ba["roofline"],
         }
         if world > 1 or args.force_dist:
-            line["allreduce"] = dict(ms_per_step=ba["allreduce_ms_per_step"], bytes=ba["allreduce_bytes"],
-                                     via="vs_comm_allreduce_sum (RCCL, library stream)" if comm is not None
-                                     else "torch.distributed " + backend)
+            via = "RCCL on the library's stream (vs_comm)" if comm is not None else "torch.distributed " + backend
+            line["exchange"] = dict(ms_per_step=ba["exchange_ms_per_step"], send_bytes_per_rank=ba["exchange_send_bytes"],
+                                    recv_bytes_per_rank=ba["exchange_recv_bytes"], via="vs_ba_exchange_reduced: all-gather of row segments, " + via,
+                                    whole_buffer_allreduce=dict(ms_per_step=ba["allreduce_ms_per_step"], bytes=ba["allreduce_bytes"], via=via))
         if "two_streams" in ba:
             extra["ba_two_streams"] = ba["two_streams"]
         if "matcher" in extra:   # second half of the metric: SuperPoint query rows matched per second

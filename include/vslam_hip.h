@@ -160,6 +160,23 @@ int vs_comm_create(vs_comm_handle *c, int32_t rank, int32_t world, const void *i
 int vs_comm_destroy(vs_comm_handle c);
 /* In-place sum of n doubles at a device pointer across the ranks, enqueued on hip_stream. */
 int vs_comm_allreduce_sum(vs_comm_handle c, double *device_buf, int64_t n, void *hip_stream);
+/* Combines the shards' partial reduce buffers (no counterpart in the reference, which is one
+ * process): after it every rank's vs_ba_reduce_buffer() holds the sum over the ranks.  The
+ * landmarks of a shard see one contiguous range of cameras, so a rank sends only the rows of that
+ * range (diagonal blocks, the off-diagonal blocks of those rows, right-hand side, diag(U), g_c,
+ * the cost): one all-gather of these segments through the communicator (RCCL, on the handle's
+ * stream) or the gather callback, then every rank adds the pieces in rank order.  With neither, the
+ * whole buffer goes through the all-reduce callback.  vs_ba_lm_step / vs_ba_solve call it
+ * themselves; it is public so that a caller who drives vs_ba_linearize can finish the sum. */
+int vs_ba_exchange_reduced(vs_ba_handle h);
+/* Doubles this rank sends in vs_ba_exchange_reduced and doubles every rank receives (ranks x the
+ * longest segment); zeros for an unsharded handle. */
+int vs_ba_exchange_size(vs_ba_handle h, int64_t *send_doubles, int64_t *total_doubles);
+/* Gather callback for callers that bring their own collective: every rank's n doubles at device
+ * pointer `send` must arrive at `recv` + rank * n on every rank; returns 0.  The handle's stream is
+ * synchronised before the call. */
+typedef int (*vs_allgather_fn)(void *user, const void *send, void *recv, int64_t n_doubles);
+int vs_ba_set_allgather(vs_ba_handle h, vs_allgather_fn fn, void *user);
 /* NULL detaches.  The handle must have been given this rank's shard
  * (vs_ba_set_observations_sharded with the communicator's rank and world). */
 int vs_ba_set_comm(vs_ba_handle h, vs_comm_handle c);

@@ -52,7 +52,7 @@ def test_device_build_equals_host_build(monkeypatch, case, kw):
         step = None
         if "world" not in kw:
             step = p.lm_step(1e4)
-        got.append((br, bc, S, rhs, cost, Vinv6, gp, res, Jc, Jp, ecost, step, p.points()))
+        got.append((br, bc, S, rhs, cost, Vinv6, gp, res, Jc, Jp, np.array(p.exchange_size() + (ecost,)), step, p.points()))
         p.close()
     a, b = got
     for x, y in zip(a[:11], b[:11]):

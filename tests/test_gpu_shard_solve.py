@@ -172,3 +172,69 @@ def test_sharded_handles_give_the_same_answers_when_used_twice():
     lone = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=1, world=2)
     with pytest.raises(Exception):
         lone.lm_step(1e4)
+
+
+class TwoRankAllGather:
+    """All-gather across two threads: each rank copies its piece into both ranks' receive buffers."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.barrier = threading.Barrier(2, timeout=60)
+        self.recv = [None, None]
+        self.calls = [0, 0]
+        self.doubles = [0, 0]
+
+    def hook(self, rank):
+        def fn(send_ptr, recv_ptr, n):
+            self.recv[rank] = vdist.device_tensor(recv_ptr, 2 * n)
+            self.barrier.wait()
+            send = vdist.device_tensor(send_ptr, n)
+            for r in range(2):
+                self.recv[r][rank * n:(rank + 1) * n] = send
+            self.torch.cuda.synchronize()
+            self.barrier.wait()
+            self.calls[rank] += 1
+            self.doubles[rank] = n
+        return fn
+
+
+@pytest.mark.parametrize("scene", ["c1", "banded"])
+def test_segment_exchange_equals_the_all_reduce(scene):
+    """vs_ba_exchange_reduced through the gather callback (each rank sends only the rows its
+    landmarks touch) against the whole-buffer all-reduce: the same reduce buffer on both ranks,
+    equal to the unsharded one; the solve takes the same iterates; the payload is a fraction of
+    the buffer when the trajectory is long."""
+    import torch
+    sc = synth.make_ba_config("c1", seed=13) if scene == "c1" else synth.make_ba_scene(200, 6000, 4, band=10, seed=23)
+    dc = np.full(6 * sc.Nc, 1e-3); dp = np.full(3 * sc.Np, 1e-3)
+    whole = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    whole.linearize(None, dp)
+    ptr_w, n = whole.reduce_buffer()
+    want = vdist.device_tensor(ptr_w, n).cpu().numpy().copy()
+    ag, ar = TwoRankAllGather(torch), TwoRankAllReduce(torch)
+    parts = [BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, rank=r, world=2) for r in range(2)]
+    for r in range(2):
+        parts[r].set_allgather(ag.hook(r))
+        parts[r].set_allreduce(ar.hook(r))
+
+    def lin_and_exchange(r):
+        parts[r].linearize(None, dp)
+        parts[r].exchange_reduced()
+        p, m = parts[r].reduce_buffer()
+        return vdist.device_tensor(p, m).cpu().numpy().copy()
+    got = run_two_ranks(lin_and_exchange)
+    assert np.array_equal(got[0], got[1])                         # the pieces are added in rank order on both ranks
+    assert rel(got[0], want) < 1e-12
+    assert ag.calls == [1, 1] and ar.calls == [0, 0]              # the buffer went through the gather only
+    sizes = [parts[r].exchange_size() for r in range(2)]
+    assert sizes[0][1] == sizes[1][1] == 2 * ag.doubles[0]
+    if scene == "banded":
+        assert max(s[0] for s in sizes) < 0.6 * n                 # each rank sends about half of the buffer
+    ref = whole.solve(max_num_iterations=6)
+    outs = run_two_ranks(lambda r: parts[r].solve(max_num_iterations=6))
+    for r in range(2):
+        assert outs[r]["iterations"] == ref["iterations"] and outs[r]["successful_steps"] == ref["successful_steps"]
+        assert abs(outs[r]["final_cost"] - ref["final_cost"]) < 1e-9 * ref["final_cost"]
+        assert rel(parts[r].points(), whole.points()) < 1e-7
+    assert outs[0] == outs[1] and np.array_equal(parts[0].cameras()[0], parts[1].cameras()[0])
+    assert ag.calls[0] > 2

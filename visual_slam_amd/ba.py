@@ -147,6 +147,30 @@ class BAProblem:
         self._cb = _lib.ALLREDUCE_FN(tramp)
         check(self.lib.vs_ba_set_allreduce(self.h, self._cb, None))
 
+    def set_allgather(self, fn):
+        """fn(send_ptr:int, recv_ptr:int, n_doubles:int) -> None must place every rank's n doubles
+        at recv + rank * n on every rank (vs_ba_exchange_reduced's transport)."""
+        def tramp(_user, send, recv, n):
+            try:
+                fn(int(send), int(recv), int(n))
+                return 0
+            except Exception:   # never unwind through the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb_gather = _lib.ALLGATHER_FN(tramp)
+        check(self.lib.vs_ba_set_allgather(self.h, self._cb_gather, None))
+
+    def exchange_reduced(self):
+        """Sum of the shards' partial reduce buffers, on every rank (after linearize)."""
+        check(self.lib.vs_ba_exchange_reduced(self.h))
+
+    def exchange_size(self):
+        """(doubles this rank sends, doubles every rank receives) in exchange_reduced."""
+        a = C.c_int64(0); b = C.c_int64(0)
+        check(self.lib.vs_ba_exchange_size(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def lm_step(self, radius=1e4, fetch=True):
         """One LM step.  fetch=False leaves the step on the device (as inside vs_ba_solve) and
         returns only the model cost change."""

@@ -96,6 +96,13 @@ struct vs_ba {
     int64_t red_len = 0;
     vs_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    vs_allgather_fn allgather = nullptr;
+    void *allgather_user = nullptr;
+    // what each shard sends when the reduce buffers are combined (exchange_reduced)
+    std::vector<ShardSeg> segs;
+    DevBuf<ShardSeg> d_segs;
+    int64_t seg_stride = 0;
+    DevBuf<real> seg_send, seg_recv;
     vs_comm *comm = nullptr;
     const void *known_dev_dc = nullptr, *known_dev_dp = nullptr;   // damping pointers already classified as device memory
     DevBuf<real> eval_res, eval_Jc, eval_Jp;                       // staging of vs_ba_evaluate, grown on demand
@@ -213,6 +220,28 @@ int rows_to_caller(vs_ba *h, int width, const real *src, int src_stride, int src
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, h->Np, width, h->new2old.p, src,
                        src_stride, src_off, dst);
     return launch_check("scatter_rows_kernel");
+}
+
+// Segments of the reduce buffer every shard sends (see ShardSeg): block ranges from the sorted
+// block rows, the common stride, and the table the summing kernel reads.
+int finish_segments(vs_ba *h, const std::vector<int> &cam_lo, const std::vector<int> &cam_hi)
+{
+    h->segs.assign((size_t)h->world, ShardSeg{ 0, -1, 0, 0 });
+    h->seg_stride = 0;
+    if (h->world <= 1) return VS_OK;
+    for (int r = 0; r < h->world; r++) {
+        ShardSeg g{ cam_lo[r], cam_hi[r], 0, 0 };
+        if (g.cam_hi >= g.cam_lo) {
+            g.blk_lo = (int)(std::lower_bound(h->h_brow.begin(), h->h_brow.end(), g.cam_lo) - h->h_brow.begin());
+            g.blk_hi = (int)(std::upper_bound(h->h_brow.begin(), h->h_brow.end(), g.cam_hi) - h->h_brow.begin());
+        } else { g.cam_lo = 0; g.cam_hi = -1; }
+        h->segs[r] = g;
+        h->seg_stride = std::max(h->seg_stride, seg_len(g));
+    }
+    h->seg_stride = (h->seg_stride + 1) / 2 * 2;
+    VS_TRY(h->d_segs.upload(h->segs.data(), h->segs.size(), h->stream));
+    VS_HIP(hipStreamSynchronize(h->stream));
+    return VS_OK;
 }
 
 // Work-item lists of the block kernels from the camera-major and camera-pair entry counts
@@ -490,11 +519,24 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         if (pmap.insert(key)) { pmap.set(key, (int32_t)uniq.size()); uniq.push_back(key); }
         return pmap.get(key);
     };
+    // camera range seen by the landmarks of every shard (what a rank sends in exchange_reduced)
+    std::vector<int> rank_first((size_t)h->world + 1, Np), rank_cam_lo((size_t)h->world, Nc), rank_cam_hi((size_t)h->world, -1);
+    for (int r = 0; r < h->world; r++) {
+        const int64_t target = Ng * r / h->world;
+        rank_first[r] = std::min((int)(std::lower_bound(gptr.begin(), gptr.end(), target) - gptr.begin()), Np);
+    }
+    rank_first[0] = 0;
+    int rank_of_j = 0;
     for (int j = 0; j < Np; j++) {
         const int64_t b = gptr[j], e = gptr[j + 1];
         tmp.clear();
         for (int64_t k = b; k < e; k++) tmp.emplace_back(cam[gord[k]], gord[k]);
         std::sort(tmp.begin(), tmp.end());
+        while (rank_of_j + 1 < h->world && j >= rank_first[rank_of_j + 1]) rank_of_j++;
+        if (!tmp.empty()) {
+            rank_cam_lo[rank_of_j] = std::min(rank_cam_lo[rank_of_j], tmp.front().first);
+            rank_cam_hi[rank_of_j] = std::max(rank_cam_hi[rank_of_j], tmp.back().first);
+        }
         for (size_t a = 1; a < tmp.size(); a++)
             VS_CHECK(tmp[a].first != tmp[a - 1].first, VS_ERR_INVALID, "point %d is observed twice by camera %d", j, tmp[a].first);
         const bool local = j >= pt_lo && j < pt_hi;
@@ -567,6 +609,7 @@ int build_structure(vs_ba *h, const int32_t *cam, const int32_t *pt_user, const 
         }
     }
     lap("camera-major view");
+    VS_TRY(finish_segments(h, rank_cam_lo, rank_cam_hi));
     ItemLists lists;
     VS_TRY(make_items(h, cam_ptr.data(), bptr.data(), lists));
     std::vector<BlockItem> &items = lists.items, &diag_items = lists.diag_items, &small_items = lists.small_items;
@@ -730,8 +773,19 @@ int build_structure_device(vs_ba *h, const int32_t *cam, const int32_t *pt_user,
     hipLaunchKernelGGL(pair_count_kernel, grid(Np), dim3(256), 0, s, Np, gptr.p, npairs.p);
     VS_TRY(exclusive_sum(tmp, npairs.p, poff.p, Np, s));
     hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, s, Np, poff.p, npairs.p, &sc.p->n_pairs);
+    std::vector<int> rank_cam_lo((size_t)h->world, Nc), rank_cam_hi((size_t)h->world, -1);
+    DevBuf<int> d_rank_cam;
+    if (h->world > 1) {
+        VS_TRY(d_rank_cam.alloc(2 * (size_t)h->world));
+        hipLaunchKernelGGL(rank_camera_range_kernel, dim3(h->world), dim3(256), 0, s, Ng, Np, Nc, h->world, gptr.p, okeys.p,
+                           d_rank_cam.p, d_rank_cam.p + h->world);
+    }
     VS_TRY(launch_check("structure kernels (observations)"));
     VS_HIP(hipMemcpyAsync(hsc.p, sc.p, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    if (h->world > 1) {
+        VS_HIP(hipMemcpyAsync(rank_cam_lo.data(), d_rank_cam.p, sizeof(int) * (size_t)h->world, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipMemcpyAsync(rank_cam_hi.data(), d_rank_cam.p + h->world, sizeof(int) * (size_t)h->world, hipMemcpyDeviceToHost, s));
+    }
     VS_HIP(hipStreamSynchronize(s));
     lap("observation sort");
     {
@@ -821,6 +875,7 @@ int build_structure_device(vs_ba *h, const int32_t *cam, const int32_t *pt_user,
     h->hub = HuberObs{ -1, -1, -1, (real)h->huber_a };
     if (h->huber_a > 0.0 && hsc.p->hub_pos >= 0) { h->hub.pos = hsc.p->hub_pos; h->hub.cam = hsc.p->hub_cam; h->hub.pt = hsc.p->hub_pt; }
     lap("blocks read back");
+    VS_TRY(finish_segments(h, rank_cam_lo, rank_cam_hi));
     ItemLists lists;
     VS_TRY(make_items(h, cam_ptr.data(), bptr.data(), lists));
     h->lm_cam_span = 0;
@@ -972,6 +1027,36 @@ int cross_gpu_sum(vs_ba *h, real *buf, int64_t n)
 
 bool is_sharded(const vs_ba *h) { return h->world > 1 && (h->comm || h->allreduce); }
 
+// The shards' partial reduce buffers -> their sum, on every rank.  With a communicator or a gather
+// callback each rank sends only the segment its landmarks touch (one all-gather; the pieces are
+// added in rank order, so all ranks end with bitwise identical buffers); otherwise the whole buffer
+// is all-reduced.  VS_BA_EXCHANGE=allreduce forces the latter (measurement).
+int exchange_reduced(vs_ba *h)
+{
+    if (h->world <= 1) return VS_OK;
+    bool gather = (h->comm != nullptr || h->allgather != nullptr) && h->seg_stride > 0;
+    if (const char *e = getenv("VS_BA_EXCHANGE")) gather = gather && strcmp(e, "allreduce") != 0;
+    if (!gather) return cross_gpu_sum(h, h->red.p, h->red_len);
+    hipStream_t s = h->stream;
+    const int64_t stride = h->seg_stride;
+    if (h->seg_send.n < (size_t)stride) VS_TRY(h->seg_send.alloc((size_t)stride));
+    if (h->seg_recv.n < (size_t)(stride * h->world)) VS_TRY(h->seg_recv.alloc((size_t)(stride * h->world)));
+    const ShardSeg own = h->segs[(size_t)h->rank];
+    hipLaunchKernelGGL(pack_segment_kernel, dim3(div_up(seg_len(own), 256)), dim3(256), 0, s, own, h->Nc, h->nb_off,
+                       h->red.p, h->seg_send.p);
+    VS_TRY(launch_check("pack_segment_kernel"));
+    if (h->comm) {
+        VS_TRY(comm_allgather(h->comm, h->seg_send.p, h->seg_recv.p, stride, s));
+    } else {
+        VS_HIP(hipStreamSynchronize(s));
+        const int rc = h->allgather(h->allgather_user, h->seg_send.p, h->seg_recv.p, stride);
+        VS_CHECK(rc == 0, VS_ERR_HIP, "all-gather callback failed with code %d", rc);
+    }
+    hipLaunchKernelGGL(sum_segments_kernel, dim3(div_up(h->red_len, 256)), dim3(256), 0, s, h->world, h->d_segs.p, stride,
+                       h->Nc, h->nb_off, h->seg_recv.p, h->red.p);
+    return launch_check("sum_segments_kernel");
+}
+
 // A shard of a multi-GPU problem cannot take an LM step on its own: its reduced system is a
 // partial sum.
 int ensure_sum_path(const vs_ba *h)
@@ -1010,7 +1095,7 @@ int unscaled_pass(vs_ba *h)
     int rc = linearize(h, h->t.p, h->rpy.p, h->pts.p, none, nullptr, true);
     h->fix_points = fp;
     VS_TRY(rc);
-    VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+    VS_TRY(exchange_reduced(h));
     hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(6 * h->Nc, 256)), dim3(256), 0, h->stream, 6 * h->Nc, h->udiag(), h->scale_c.p);
     hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(3 * (int64_t)h->Np, 256)), dim3(256), 0, h->stream, 3 * h->Np, h->Vdiag.p, h->scale_p.p);
     VS_TRY(launch_check("jacobi_scale_kernel"));
@@ -1031,7 +1116,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
     if (!(h->prelin && h->prelin_radius == radius)) {
         PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)min_d, (real)max_d };
         VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
-        VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+        VS_TRY(exchange_reduced(h));
     }
     h->prelin = false;   // the camera damping below changes the reduce buffer in place
     hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * Nc, 256)), dim3(256), 0, s, Nc, h->udiag(),
@@ -1493,6 +1578,29 @@ int vs_ba_set_allreduce(vs_ba_handle h, vs_allreduce_fn fn, void *user)
     return VS_OK;
 }
 
+int vs_ba_set_allgather(vs_ba_handle h, vs_allgather_fn fn, void *user)
+{
+    VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
+    h->allgather = fn; h->allgather_user = user;
+    return VS_OK;
+}
+
+int vs_ba_exchange_reduced(vs_ba_handle h)
+{
+    VS_TRY(ensure_state(h));
+    VS_CHECK(h->linearized, VS_ERR_STATE, "nothing linearised yet");
+    VS_TRY(ensure_sum_path(h));
+    return exchange_reduced(h);
+}
+
+int vs_ba_exchange_size(vs_ba_handle h, int64_t *send_doubles, int64_t *total_doubles)
+{
+    VS_CHECK(h && h->have_obs, VS_ERR_STATE, "observations not set");
+    if (send_doubles) *send_doubles = h->world > 1 ? seg_len(h->segs[(size_t)h->rank]) : 0;
+    if (total_doubles) *total_doubles = h->world > 1 ? h->seg_stride * h->world : 0;
+    return VS_OK;
+}
+
 int vs_ba_set_comm(vs_ba_handle h, vs_comm_handle c)
 {
     VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
@@ -1591,7 +1699,7 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
                     // gradient does not depend on the damping)
                     PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)o.min_lm_diagonal, (real)o.max_lm_diagonal };
                     VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
-                    VS_TRY(cross_gpu_sum(h, h->red.p, h->red_len));
+                    VS_TRY(exchange_reduced(h));
                     h->prelin = true;
                     h->prelin_radius = radius;
                     VS_TRY(gradient_max_enqueue(h));

@@ -255,6 +255,40 @@ tile_span_kernel(int n_tiles, int Np, int Nc, int tile_landmarks, const int *__r
     }
 }
 
+// Camera range seen by the landmarks of every shard (one workgroup per rank): the shard bounds
+// as shard_bounds_kernel takes them, then min / max of the cameras of its sorted observations.
+__global__ void __launch_bounds__(256)
+rank_camera_range_kernel(int Ng, int Np, int Nc, int world, const int *__restrict__ gptr,
+                         const unsigned long long *__restrict__ okeys, int *cam_lo, int *cam_hi)
+{
+    __shared__ int s_mn[4], s_mx[4];
+    const int r = blockIdx.x;
+    auto bound = [&](int q) {
+        const long long target = (long long)Ng * q / world;
+        int lo = 0, hi = Np + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (gptr[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    int pt_lo = min(bound(r), Np), pt_hi = r == world - 1 ? Np : min(bound(r + 1), Np);
+    if (pt_hi < pt_lo) pt_hi = pt_lo;
+    int mn = Nc, mx = -1;
+    for (int p = gptr[pt_lo] + (int)threadIdx.x; p < gptr[pt_hi]; p += 256) {
+        const int c = (int)(unsigned)(okeys[p] & 0xffffffffull);
+        mn = min(mn, c); mx = max(mx, c);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off, 64)); mx = max(mx, __shfl_xor(mx, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cam_lo[r] = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
+        cam_hi[r] = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+    }
+}
+
 inline int bits_for(long long n_values)      // bits that hold values in [0, n_values)
 {
     int b = 1;

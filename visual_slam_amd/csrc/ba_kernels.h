@@ -1373,6 +1373,77 @@ __global__ void scatter_rows_kernel(int Np, int width, const int *__restrict__ m
     dst[(int64_t)width * map[j] + k] = src[(int64_t)src_stride * j + src_off + k];
 }
 
+// Multi-GPU exchange of the reduce buffer.  The landmarks of shard r see the cameras
+// [cam_lo, cam_hi] only (landmarks are numbered by first camera), so its partial buffer is zero
+// outside the diagonal blocks, right-hand side, diag(U) and g_c of those cameras, the off-diagonal
+// blocks of those rows [blk_lo, blk_hi) and the cost: that is what a rank sends.
+struct ShardSeg {
+    int cam_lo, cam_hi;      // inclusive; cam_hi < cam_lo: the shard is empty
+    int blk_lo, blk_hi;      // off-diagonal blocks of the rows [cam_lo, cam_hi]
+};
+__host__ __device__ __forceinline__ int64_t seg_len(const ShardSeg &g)
+{
+    const int64_t nc = g.cam_hi >= g.cam_lo ? g.cam_hi - g.cam_lo + 1 : 0, nb = g.blk_hi - g.blk_lo;
+    return 54 * nc + 36 * nb + 1;      // 36 + 18 per camera, 36 per block, the cost
+}
+
+// This rank's segment -> out[0, seg_len): [S_diag rows | S_off blocks | rhs | diag(U) | g_c | cost]
+__global__ void pack_segment_kernel(ShardSeg g, int Nc, int nb_off, const real *__restrict__ red, real *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nc = g.cam_hi >= g.cam_lo ? g.cam_hi - g.cam_lo + 1 : 0, nb = g.blk_hi - g.blk_lo;
+    const int64_t n = 54 * nc + 36 * nb + 1;
+    if (i >= n) return;
+    const RedView rv = red_view(const_cast<real *>(red), Nc, nb_off);
+    int64_t k = i;
+    real v;
+    if (k < 36 * nc) v = rv.S_diag[36 * (int64_t)g.cam_lo + k];
+    else if ((k -= 36 * nc) < 36 * nb) v = rv.S_off[36 * (int64_t)g.blk_lo + k];
+    else if ((k -= 36 * nb) < 6 * nc) v = rv.rhs[6 * (int64_t)g.cam_lo + k];
+    else if ((k -= 6 * nc) < 6 * nc) v = rv.udiag[6 * (int64_t)g.cam_lo + k];
+    else if ((k -= 6 * nc) < 6 * nc) v = rv.gc[6 * (int64_t)g.cam_lo + k];
+    else v = *rv.cost;
+    out[i] = v;
+}
+
+// red[i] = sum over the ranks whose segment covers element i, in rank order (every rank forms the
+// same sums from the same gathered pieces: bitwise identical buffers).  recv: world x stride.
+__global__ void sum_segments_kernel(int world, const ShardSeg *__restrict__ segs, int64_t stride, int Nc, int nb_off,
+                                    const real *__restrict__ recv, real *__restrict__ red)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t red_len = 54 * (int64_t)Nc + 36 * (int64_t)nb_off + 1;
+    if (i >= red_len) return;
+    // element i of the reduce buffer: part (0 S_diag, 1 S_off, 2 rhs, 3 diag(U), 4 g_c, 5 cost), owner
+    // (camera or block), offset inside the owner's values
+    int part, owner, sub;
+    int64_t k = i;
+    if (k < 36 * (int64_t)Nc) { part = 0; owner = (int)(k / 36); sub = (int)(k % 36); }
+    else if ((k -= 36 * (int64_t)Nc) < 36 * (int64_t)nb_off) { part = 1; owner = (int)(k / 36); sub = (int)(k % 36); }
+    else if ((k -= 36 * (int64_t)nb_off) < 6 * (int64_t)Nc) { part = 2; owner = (int)(k / 6); sub = (int)(k % 6); }
+    else if ((k -= 6 * (int64_t)Nc) < 6 * (int64_t)Nc) { part = 3; owner = (int)(k / 6); sub = (int)(k % 6); }
+    else if ((k -= 6 * (int64_t)Nc) < 6 * (int64_t)Nc) { part = 4; owner = (int)(k / 6); sub = (int)(k % 6); }
+    else { part = 5; owner = 0; sub = 0; }
+    real sum = real(0);
+    for (int r = 0; r < world; r++) {
+        const ShardSeg g = segs[r];
+        const int64_t nc = g.cam_hi >= g.cam_lo ? g.cam_hi - g.cam_lo + 1 : 0, nb = g.blk_hi - g.blk_lo;
+        int64_t off;
+        if (part == 1) {
+            if (owner < g.blk_lo || owner >= g.blk_hi) continue;
+            off = 36 * nc + 36 * (int64_t)(owner - g.blk_lo) + sub;
+        } else if (part == 5) {
+            off = 54 * nc + 36 * nb;
+        } else {
+            if (owner < g.cam_lo || owner > g.cam_hi) continue;
+            const int64_t c = owner - g.cam_lo;
+            off = part == 0 ? 36 * c + sub : 36 * nc + 36 * nb + 6 * nc * (part - 2) + 6 * c + sub;
+        }
+        sum += recv[(int64_t)r * stride + off];
+    }
+    red[i] = sum;
+}
+
 // Zeroes the points outside [pt_lo, pt_hi) (the shard sum that follows gathers all points).
 __global__ void mask_points_kernel(int Np, int pt_lo, int pt_hi, real *__restrict__ pts)
 {

@@ -19,6 +19,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -41,8 +42,9 @@ int load_rccl()
     g_api.CommInitRank = (decltype(g_api.CommInitRank))dlsym(lib, "ncclCommInitRank");
     g_api.CommDestroy = (decltype(g_api.CommDestroy))dlsym(lib, "ncclCommDestroy");
     g_api.AllReduce = (decltype(g_api.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_api.AllGather = (decltype(g_api.AllGather))dlsym(lib, "ncclAllGather");
     g_api.GetErrorString = (decltype(g_api.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    VS_CHECK(g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce && g_api.GetErrorString,
+    VS_CHECK(g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce && g_api.AllGather && g_api.GetErrorString,
              VS_ERR_UNSUPPORTED, "librccl lacks a required symbol");
     g_api.ok = true;
     return VS_OK;
@@ -74,6 +76,15 @@ int comm_allreduce_min_u64(vs_comm *c, unsigned long long *buf, int64_t n, hipSt
     VS_CHECK(c && c->comm, VS_ERR_STATE, "communicator not initialised");
     if (n <= 0) return VS_OK;
     VS_RCCL(g_api.AllReduce(buf, buf, (size_t)n, ncclUint64, ncclMin, c->comm, s));
+    return VS_OK;
+}
+
+// every rank's n doubles at `send` end up at recv + rank * n on every rank
+int comm_allgather(vs_comm *c, const double *send, double *recv, int64_t n, hipStream_t s)
+{
+    VS_CHECK(c && c->comm, VS_ERR_STATE, "communicator not initialised");
+    if (n <= 0) return VS_OK;
+    VS_RCCL(g_api.AllGather(send, recv, (size_t)n, ncclDouble, c->comm, s));
     return VS_OK;
 }
 

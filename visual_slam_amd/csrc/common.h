@@ -117,6 +117,7 @@ struct PinnedBuf {
 // on stream s (no host synchronisation).
 int comm_allreduce(vs_comm *c, double *buf, int64_t n, bool take_max, hipStream_t s);
 int comm_allreduce_min_u64(vs_comm *c, unsigned long long *buf, int64_t n, hipStream_t s);
+int comm_allgather(vs_comm *c, const double *send, double *recv, int64_t n, hipStream_t s);
 int comm_rank(const vs_comm *c);
 int comm_world(const vs_comm *c);
 

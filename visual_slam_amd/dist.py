@@ -72,6 +72,23 @@ def attach_allreduce(ba, group=None):
     return ba
 
 
+def attach_allgather(ba, group=None):
+    """Makes this rank's BAProblem combine the reduce buffers by sending only the segment its
+    landmarks touch (vs_ba_exchange_reduced) through torch.distributed's all_gather."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(send_ptr, recv_ptr, n):
+        world = dist.get_world_size(group)
+        send = device_tensor(send_ptr, n)
+        recv = device_tensor(recv_ptr, n * world)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        torch.cuda.current_stream().synchronize()
+
+    ba.set_allgather(hook)
+    return ba
+
+
 def allreduce_sum_(array, group=None):
     """In-place sum of a numpy float64 array across ranks (host path used by the CPU tests)."""
     import torch

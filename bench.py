@@ -307,6 +307,17 @@ def bench_solve_small():
     from visual_slam_amd import synth
     from visual_slam_amd.ba import BAProblem
     out = {}
+
+    def setup_ms(sc, pts, fix):
+        """Median time of building a problem from host arrays (vs_ba_create, set_cameras, set_points,
+        set_observations) and destroying it: the reference builds a fresh Optimizer per solve."""
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            g = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, pts, sc.cam, sc.pt, sc.uv, fix_points=fix)
+            g.close()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts[2:])) * 1e3
     for name in ("c1", "c2"):
         sc = synth.make_ba_config(name, seed=0)
         for fix in (True, False):
@@ -322,7 +333,7 @@ def bench_solve_small():
                 ts.append(time.perf_counter() - t0)
             gpu.close()
             rec = dict(gpu_ms=float(np.median(ts)) * 1e3, iterations=int(g["iterations"]),
-                       final_cost=float(g["final_cost"]))
+                       final_cost=float(g["final_cost"]), setup_ms=setup_ms(sc, pts, fix))
             out["%s_%s" % (name, "motion_only" if fix else "full")] = rec
     # ten LM iterations of full BA at config 4 (the CPU oracle forms the dense reduced system there:
     # no CPU figure beside it)
@@ -339,7 +350,49 @@ def bench_solve_small():
     gpu.close()
     out["c4_full_10_iterations"] = dict(gpu_ms=float(np.median(ts)) * 1e3, iterations=int(g["iterations"]),
                                         successful_steps=int(g["successful_steps"]),
-                                        initial_cost=float(g["initial_cost"]), final_cost=float(g["final_cost"]))
+                                        initial_cost=float(g["initial_cost"]), final_cost=float(g["final_cost"]),
+                                        setup_ms=setup_ms(sc, sc.pts0, False))
+    out["adapter"] = bench_adapter()
+    return out
+
+
+def bench_adapter():
+    """The drop-in path end to end: the C++ adapter with the reference's Optimizer interface
+    (addPose / addKeys / addPoints / addReprojectionEdges / solve / getPose, a fresh Optimizer per
+    solve as in Tracking::solveCamera, src/core/tracking.cc:79-120) on a 10-keyframe, 500-point
+    window, timed inside tests/cpp/adapter_harness (median wall time of one whole sequence)."""
+    import struct
+    import subprocess
+    import tempfile
+    from visual_slam_amd import optimizer as vo, synth
+    root = os.path.dirname(os.path.abspath(__file__))
+    harness = os.path.join(root, "tests", "cpp", "adapter_harness")
+    if not os.path.exists(harness):
+        return dict(note="tests/cpp/adapter_harness not built")
+    out = {}
+    sc, tracks, keys = synth.make_tracks_scene(10, 500, seed=3)
+    nf, npnt = tracks.shape
+    poses = np.zeros((nf, 7), np.float32)
+    for f in range(nf):
+        poses[f, :3] = sc.t0[f]
+        poses[f, 3:] = vo.rpy_to_quat_f32(sc.rpy0[f].astype(np.float32))
+    with tempfile.TemporaryDirectory() as tmp:
+        for fix in (1, 0):
+            pw = (sc.pts_gt if fix else sc.pts0).astype(np.float32)
+            blob = struct.pack("<4i", 0, nf, npnt, fix) + poses.tobytes()
+            for f in range(nf):
+                blob += struct.pack("<i", len(keys[f])) + keys[f].astype(np.int32).tobytes()
+            blob += tracks.astype(np.int32).tobytes() + pw.tobytes()
+            fi, fo = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+            with open(fi, "wb") as f:
+                f.write(blob)
+            r = subprocess.run([harness, fi, fo], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, VS_HARNESS_REPEAT="30"))
+            ms = [float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("adapter_ms_median")]
+            key = "motion_only" if fix else "full"
+            out[key] = dict(adapter_ms=ms[0] if ms and r.returncode == 0 else None,
+                            observations=int((tracks >= 0).sum()),
+                            note="Optimizer built, solved and read back; 10 keyframes x 500 tracked points")
     return out
 
 

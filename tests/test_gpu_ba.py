@@ -383,3 +383,32 @@ def test_optimizer_mirror_runs_the_reference_call_order(orc):
     for f in range(6):
         pose = opt.getPose(f)
         assert np.abs(pose.translation - ref.t[f].astype(np.float32)).max() < 1e-5
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_one_launch_motion_only_solver_equals_the_general_path(orc, monkeypatch, seed):
+    """Motion-only BA of a small window runs as one kernel launch (the reference's live mode,
+    Tracking::solveCamera); the same solve through the general multi-kernel path and through the
+    oracle: same iterations and decisions, same cameras.  The first edge sits in its Huber region."""
+    sc = synth.make_ba_config("c1", seed=seed)
+    sc.uv = sc.uv.copy()
+    sc.uv[0] += 300.0
+    ref, fast = both(orc, sc, pts=sc.pts_gt, fix_points=True, huber_a=100.0)
+    slow = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts_gt, sc.cam, sc.pt, sc.uv, fix_points=True, huber_a=100.0)
+    out_f = fast.solve()
+    monkeypatch.setenv("VS_BA_NO_SMALL_SOLVER", "1")
+    out_s = slow.solve()
+    monkeypatch.delenv("VS_BA_NO_SMALL_SOLVER")
+    out_r = ref.solve()
+    for k in ("termination", "iterations", "successful_steps"):
+        assert out_f[k] == out_s[k] == out_r[k], k
+    assert abs(out_f["final_cost"] - out_s["final_cost"]) < 1e-10 * out_s["final_cost"]
+    assert abs(out_f["final_cost"] - out_r["final_cost"]) < 1e-9 * out_r["final_cost"]
+    assert abs(out_f["radius"] - out_s["radius"]) < 1e-9 * out_s["radius"]
+    tf, rf = fast.cameras(); ts, rs = slow.cameras()
+    assert rel(tf, ts) < 1e-9 and rel(rf, rs) < 1e-9
+    assert rel(tf, ref.t) < 1e-6 and rel(rf, ref.rpy) < 1e-6
+    # a step after the solve uses the scaling the solve left behind, like the general path
+    df, _, mf = fast.lm_step(1e3)
+    ds, _, ms = slow.lm_step(1e3)
+    assert rel(df, ds) < 1e-7 and abs(mf - ms) < 1e-7 * abs(ms)

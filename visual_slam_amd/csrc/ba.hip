@@ -13,6 +13,7 @@
 #include "dense_solve.h"
 #include "bcr_solve.h"
 #include "ba_build.h"
+#include "ba_small.h"
 
 using namespace vs;
 
@@ -121,6 +122,8 @@ struct vs_ba {
     // Small parameter uploads pass through page-locked staging owned by the handle, so the setters
     // need not wait for the copy: [t | rpy | points].  busy[r]: a copy out of region r may still be
     // in flight (r = 0 cameras, 1 points, 2 the arena staging).
+    DevBuf<SmallOut> small_out;              // motion_only_solve_kernel's summary
+    PinnedBuf<SmallOut> small_host;
     PinnedBuf<real> param_stage;
     bool busy[3] = { false, false, false };
 
@@ -1641,6 +1644,26 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
     vs_lm_options o;
     if (opts) o = *opts; else vs_lm_default_options(&o);
     hipStream_t s = h->stream;
+    // Motion-only BA of a small window (the reference's live mode): the whole loop in one launch
+    if (h->fix_points && h->world == 1 && h->Nc <= kSmallMaxCams && h->No > 0 && h->No <= kSmallMaxObs &&
+        getenv("VS_BA_NO_SMALL_SOLVER") == nullptr) {
+        if (!h->small_out.p) VS_TRY(h->small_out.alloc(1));
+        if (!h->small_host.p) VS_TRY(h->small_host.alloc(1));
+        hipLaunchKernelGGL(motion_only_solve_kernel, dim3(1), dim3(kSmallThreads), 0, s, h->Nc, h->K, h->t.p, h->rpy.p,
+                           h->pts.p, h->cam_ptr.p, h->cpt.p, h->cuv.p, h->cam_used.p, h->hub, o, h->scale_c.p, h->small_out.p);
+        VS_TRY(launch_check("motion_only_solve_kernel"));
+        VS_HIP(hipMemcpyAsync(h->small_host.p, h->small_out.p, sizeof(SmallOut), hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        h->busy[0] = h->busy[1] = h->busy[2] = false;
+        h->linearized = false; h->prelin = false; h->have_scale = true;
+        if (summary) {
+            const SmallOut &q = *h->small_host.p;
+            summary->iterations = q.iterations; summary->successful_steps = q.successful_steps;
+            summary->termination = q.termination; summary->initial_cost = q.initial_cost;
+            summary->final_cost = q.final_cost; summary->final_radius = q.final_radius;
+        }
+        return VS_OK;
+    }
     double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
     int it = 0, term = 1, nsucc = 0, invalid = 0;
     double cost = 0.0, cost0 = 0.0;

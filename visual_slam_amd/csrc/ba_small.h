@@ -1,0 +1,297 @@
+// Motion-only bundle adjustment of a small window in ONE launch (included by ba.hip only).
+//
+// The reference's live mode is Tracking::solveCamera (src/core/tracking.cc:79-120): every point is
+// constant (fix_camera_or_point = true, src/core/optimizer.cc:134-137), a handful of keyframes, a
+// few thousand observations, ceres::Solve with its default Levenberg-Marquardt loop -- twice per
+// frame.  With the points fixed the normal equations are one 6x6 block per camera, so the whole
+// loop (linearise, damp, solve, candidate cost, accept / reject, trust-region update, the three
+// termination tests) fits one workgroup: no launch, copy or host synchronisation per iteration.
+// The general path spends ~60 us per iteration on a dozen launches at this size; this kernel
+// spends a few.  The loop is the one vs_ba_solve runs on the host (same tests in the same order).
+#pragma once
+#include "ba_kernels.h"
+
+namespace vs {
+
+constexpr int kSmallThreads = 512;     // two waves per SIMD: 256 registers per lane for the 33 accumulators and the 6x6 solve
+constexpr int kSmallMaxCams = 128;
+constexpr int kSmallMaxObs = 16384;
+
+struct SmallOut {            // written by thread 0
+    real initial_cost, final_cost, final_radius;
+    int iterations, successful_steps, termination, pad;
+};
+
+// sum over the wave of NV per-lane values, every lane ends with the totals (butterfly order: fixed)
+template <int NV>
+__device__ __forceinline__ void wave_sum_all(real *v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < NV; i++) v[i] += __shfl_xor(v[i], off, 64);
+}
+
+// block-wide sum, result returned to every thread (scratch: >= 16 reals; two barriers)
+__device__ __forceinline__ real block_sum_all(real v, real *scratch)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    real s = real(0);
+#pragma unroll
+    for (int i = 0; i < kSmallThreads / 64; i++) s += scratch[i];
+    return s;
+}
+
+__global__ void __launch_bounds__(kSmallThreads)
+motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restrict__ rpy_io,
+                         const real *__restrict__ pts, const int *__restrict__ cam_ptr,
+                         const int *__restrict__ cpt, const real *__restrict__ cuv,
+                         const unsigned char *__restrict__ cam_used, HuberObs hub, vs_lm_options opt,
+                         real *__restrict__ scale_out, SmallOut *__restrict__ out)
+{
+    __shared__ CamData cams[kSmallMaxCams], cams2[kSmallMaxCams];
+    __shared__ real x[6 * kSmallMaxCams], x2[6 * kSmallMaxCams], scale[6 * kSmallMaxCams], dc[6 * kSmallMaxCams];
+    __shared__ real S[kSmallMaxCams][21], gc[6 * kSmallMaxCams], U[6 * kSmallMaxCams];
+    __shared__ real scratch[kSmallThreads / 64], mccv[kSmallMaxCams];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kSmallThreads / 64;
+
+    for (int i = tid; i < 6 * Nc; i += kSmallThreads) {
+        const int c = i / 6, k = i % 6;
+        x[i] = k < 3 ? t_io[3 * c + k] : rpy_io[3 * c + k - 3];
+    }
+    __syncthreads();
+    auto build_cams = [&](const real *par, CamData *dst) {
+        for (int c = tid; c < Nc; c += kSmallThreads) {
+            real sr, cr, sp, cp, sy, cy;
+            sincos(par[6 * c + 3], &sr, &cr);
+            sincos(par[6 * c + 4], &sp, &cp);
+            sincos(par[6 * c + 5], &sy, &cy);
+            dst[c] = cam_from_sincos(par + 6 * c, 0, sr, cr, sp, cp, sy, cy);      // the translation leads a camera's six parameters
+        }
+        __syncthreads();
+    };
+
+    // cost 0.5 sum rho(|r|^2) at camera records `cd` (every thread gets the total)
+    auto cost_at = [&](const CamData *cd) -> real {
+        real acc = real(0);
+        for (int c = wave; c < Nc; c += kWaves) {
+            const CamData cam = cd[c];
+            for (int k = cam_ptr[c] + lane; k < cam_ptr[c + 1]; k += 64) {
+                const int j = cpt[k];
+                const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
+                const double2 uv = *reinterpret_cast<const double2 *>(cuv + 2 * (int64_t)k);
+                ObsLin o;
+                project_obs(cam, P, uv.x, uv.y, K, o);
+                real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
+                if (c == hub.cam && j == hub.pt) (void)huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);
+                acc += hr;
+            }
+        }
+        return block_sum_all(acc, scratch);
+    };
+
+    // J_c^T J_c (upper triangle, 21), g_c = J_c^T r (6), diag (6) per camera and the cost, at `cams`
+    auto linearise = [&]() -> real {
+        real cost_acc = real(0);
+        for (int c = wave; c < Nc; c += kWaves) {
+            const CamData cam = cams[c];
+            real a[33];
+#pragma unroll
+            for (int v = 0; v < 33; v++) a[v] = real(0);
+            for (int k = cam_ptr[c] + lane; k < cam_ptr[c + 1]; k += 64) {
+                const int j = cpt[k];
+                const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
+                const double2 uv = *reinterpret_cast<const double2 *>(cuv + 2 * (int64_t)k);
+                ObsLin o;
+                project_obs(cam, P, uv.x, uv.y, K, o);
+                real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
+                if (c == hub.cam && j == hub.pt) {
+                    const real w = huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);
+                    scale_lin(o, w);
+                }
+                cost_acc += hr;
+                real Jc[12];
+                camera_jac(cam, o, P, Jc);
+                int idx = 0;
+#pragma unroll
+                for (int p = 0; p < 6; p++) {
+#pragma unroll
+                    for (int q = p; q < 6; q++) { a[idx] = fma(Jc[p], Jc[q], fma(Jc[6 + p], Jc[6 + q], a[idx])); idx++; }
+                    a[21 + p] = fma(Jc[p], o.r0, fma(Jc[6 + p], o.r1, a[21 + p]));
+                    a[27 + p] = fma(Jc[p], Jc[p], fma(Jc[6 + p], Jc[6 + p], a[27 + p]));
+                }
+            }
+            wave_sum_all<33>(a);
+            if (lane == 0) {
+#pragma unroll
+                for (int v = 0; v < 21; v++) S[c][v] = a[v];
+#pragma unroll
+                for (int p = 0; p < 6; p++) { gc[6 * c + p] = a[21 + p]; U[6 * c + p] = a[27 + p]; }
+            }
+        }
+        return block_sum_all(cost_acc, scratch);
+    };
+    auto gradient_max = [&]() -> real {
+        real m = real(0);
+        for (int i = tid; i < 6 * Nc; i += kSmallThreads) m = fmax(m, fabs(gc[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+        __syncthreads();
+        if (lane == 0) scratch[wave] = m;
+        __syncthreads();
+        real r = real(0);
+#pragma unroll
+        for (int i = 0; i < kWaves; i++) r = fmax(r, scratch[i]);
+        return r;
+    };
+
+    build_cams(x, cams);
+    real cost = linearise();
+    const real cost0 = cost;
+    for (int i = tid; i < 6 * Nc; i += kSmallThreads) {
+        scale[i] = real(1) / (real(1) + sqrt(U[i]));
+        scale_out[i] = scale[i];
+    }
+    real gmax = gradient_max();
+    real radius = opt.initial_trust_region_radius, decrease_factor = real(2);
+    int it = 0, term = 1, nsucc = 0, invalid = 0;
+    bool running = gmax > opt.gradient_tolerance;
+    if (!running) term = 0;
+    // every thread carries the same loop state (all inputs of the decisions are block-wide sums)
+    while (running) {
+        if (it >= opt.max_num_iterations || radius < opt.min_trust_region_radius) {
+            term = it >= opt.max_num_iterations ? 1 : 0;
+            break;
+        }
+        it++;
+        // damped 6x6 solve per camera
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        for (int c = tid; c < Nc; c += kSmallThreads) {
+            real L[6][6], b[6];
+            int idx = 0;
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+#pragma unroll
+                for (int q = p; q < 6; q++) { L[p][q] = S[c][idx]; L[q][p] = S[c][idx]; idx++; }
+                const real s = scale[6 * c + p], s2 = s * s;
+                real xd = s2 * U[6 * c + p];
+                xd = xd < opt.min_lm_diagonal ? opt.min_lm_diagonal : xd;
+                xd = xd > opt.max_lm_diagonal ? opt.max_lm_diagonal : xd;
+                L[p][p] += xd / radius / s2;
+                b[p] = -gc[6 * c + p];
+            }
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                real d = L[j][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+                if (!(d > real(0))) { bad = true; d = real(1); }
+                d = sqrt(d);
+                L[j][j] = d;
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) {
+                    real s = L[i][j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+                    L[i][j] = s / d;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                real s = b[i];
+#pragma unroll
+                for (int k = 0; k < i; k++) s -= L[i][k] * b[k];
+                b[i] = s / L[i][i];
+            }
+#pragma unroll
+            for (int i = 5; i >= 0; i--) {
+                real s = b[i];
+#pragma unroll
+                for (int k = i + 1; k < 6; k++) s -= L[k][i] * b[k];
+                b[i] = s / L[i][i];
+            }
+            if (bad) s_bad = 1;
+            // model cost change of this camera: -(d . g + d^T (J^T J) d / 2), step norms, candidate
+            real dg = real(0), dSd = real(0);
+            idx = 0;
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+                dg += b[p] * gc[6 * c + p];
+#pragma unroll
+                for (int q = p; q < 6; q++) { dSd += (p == q ? real(1) : real(2)) * b[p] * S[c][idx] * b[q]; idx++; }
+            }
+            const bool used = cam_used[c] != 0;
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+                const real d = used ? b[p] : real(0);
+                dc[6 * c + p] = d;
+                x2[6 * c + p] = x[6 * c + p] + d;
+            }
+            mccv[c] = -(dg + real(0.5) * dSd);
+        }
+        __syncthreads();
+        real mcc_l = real(0), xn_l = real(0), sn_l = real(0);
+        for (int c = tid; c < Nc; c += kSmallThreads) {
+            mcc_l += mccv[c];
+            if (cam_used[c]) {
+#pragma unroll
+                for (int p = 0; p < 6; p++) { xn_l += x[6 * c + p] * x[6 * c + p]; sn_l += dc[6 * c + p] * dc[6 * c + p]; }
+            }
+        }
+        const real mcc = block_sum_all(mcc_l, scratch);
+        const real xnorm2 = block_sum_all(xn_l, scratch);
+        const real snorm2 = block_sum_all(sn_l, scratch);
+        const bool fail = s_bad != 0;
+        if (fail || !(mcc > real(0))) {
+            if (++invalid >= opt.max_consecutive_invalid_steps) { term = 2; break; }
+            radius *= real(0.5);
+            continue;
+        }
+        invalid = 0;
+        build_cams(x2, cams2);
+        const real cost_new = cost_at(cams2);
+        const real xn = sqrt(xnorm2), sn = sqrt(snorm2);
+        if (sn <= opt.parameter_tolerance * (xn + opt.parameter_tolerance)) { term = 0; break; }
+        const real change = cost - cost_new;
+        if (fabs(change) <= opt.function_tolerance * cost) { term = 0; break; }
+        const real rho = change / mcc;
+        if (rho > opt.min_relative_decrease) {
+            __syncthreads();
+            for (int i = tid; i < 6 * Nc; i += kSmallThreads) x[i] = x2[i];
+            for (int c = tid; c < Nc; c += kSmallThreads) cams[c] = cams2[c];
+            __syncthreads();
+            cost = cost_new; nsucc++;
+            const real y = real(2) * rho - real(1);
+            real f = real(1) - y * y * y;
+            if (f < real(1) / real(3)) f = real(1) / real(3);
+            radius = fmin(radius / f, (real)opt.max_trust_region_radius);
+            decrease_factor = real(2);
+            (void)linearise();
+            gmax = gradient_max();
+            if (gmax <= opt.gradient_tolerance) { term = 0; break; }
+        } else {
+            radius /= decrease_factor;
+            decrease_factor *= real(2);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 6 * Nc; i += kSmallThreads) {
+        const int c = i / 6, k = i % 6;
+        if (k < 3) t_io[3 * c + k] = x[i]; else rpy_io[3 * c + k - 3] = x[i];
+    }
+    if (tid == 0) {
+        out->initial_cost = cost0; out->final_cost = cost; out->final_radius = radius;
+        out->iterations = it; out->successful_steps = nsucc; out->termination = term; out->pad = 0;
+    }
+}
+
+}  // namespace vs

@@ -2,7 +2,7 @@
 # Runs on the GPU box (through gpurun): rocprofv3 kernel traces + PMC traffic passes for the
 # round's evidence.  Usage: bash tools/collect_profiles.sh <round-tag>   -> gpurun_out/profiles_<tag>/
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -28,6 +28,8 @@ run_trace lm_c5shard python3 tools/time_lm.py c5shard &&
 run_trace lm_c5 python3 tools/time_lm.py c5 &&
 run_trace solve_c4 python3 tools/time_solve.py c4 &&
 run_trace solve_c1 python3 tools/time_solve.py c1 &&
+run_trace small_c1 python3 tools/time_small.py &&
+run_trace setup python3 tools/time_setup.py c1 c2 c4 &&
 run_pmc c2_fetch FETCH_SIZE python3 tools/prof_ba.py c2 5 &&
 run_pmc c2_write WRITE_SIZE python3 tools/prof_ba.py c2 5 &&
 run_pmc c4_fetch FETCH_SIZE python3 tools/prof_ba.py c4 5 &&

@@ -13,7 +13,7 @@
 
 namespace vs {
 
-constexpr int kSmallThreads = 512;     // two waves per SIMD: 256 registers per lane for the 33 accumulators and the 6x6 solve
+constexpr int kSmallThreads = 512;     // two waves per SIMD: 256 registers per lane for the accumulators, a batch of observations and the 6x6 solve
 constexpr int kSmallMaxCams = 128;
 constexpr int kSmallMaxObs = 16384;
 
@@ -78,62 +78,92 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
         __syncthreads();
     };
 
+    // A lane's observations of one camera are fetched kBatch at a time before any of them is used
+    // (landmark index, then position and pixel): two memory latencies per batch instead of two per
+    // observation -- at this size the kernel is a chain of latencies, not of arithmetic.
+    constexpr int kBatch = 6;
+    struct Obs { real P[3]; double2 uv; int j; };
+    auto fetch_batch = [&](int k0, int kend, Obs *ob) {
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) { const int k = k0 + 64 * u; ob[u].j = k < kend ? cpt[k] : -1; }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const int k = k0 + 64 * u;
+            if (ob[u].j >= 0) {
+                const int j = ob[u].j;
+                ob[u].P[0] = pts[3 * j]; ob[u].P[1] = pts[3 * j + 1]; ob[u].P[2] = pts[3 * j + 2];
+                ob[u].uv = *reinterpret_cast<const double2 *>(cuv + 2 * (int64_t)k);
+            }
+        }
+    };
+
     // cost 0.5 sum rho(|r|^2) at camera records `cd` (every thread gets the total)
     auto cost_at = [&](const CamData *cd) -> real {
         real acc = real(0);
         for (int c = wave; c < Nc; c += kWaves) {
             const CamData cam = cd[c];
-            for (int k = cam_ptr[c] + lane; k < cam_ptr[c + 1]; k += 64) {
-                const int j = cpt[k];
-                const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
-                const double2 uv = *reinterpret_cast<const double2 *>(cuv + 2 * (int64_t)k);
-                ObsLin o;
-                project_obs(cam, P, uv.x, uv.y, K, o);
-                real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
-                if (c == hub.cam && j == hub.pt) (void)huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);
-                acc += hr;
+            const int kend = cam_ptr[c + 1];
+            for (int k0 = cam_ptr[c] + lane; k0 < kend; k0 += 64 * kBatch) {
+                Obs ob[kBatch];
+                fetch_batch(k0, kend, ob);
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    if (ob[u].j < 0) continue;
+                    ObsLin o;
+                    project_obs(cam, ob[u].P, ob[u].uv.x, ob[u].uv.y, K, o);
+                    real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
+                    if (c == hub.cam && ob[u].j == hub.pt) (void)huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);
+                    acc += hr;
+                }
             }
         }
         return block_sum_all(acc, scratch);
     };
 
-    // J_c^T J_c (upper triangle, 21), g_c = J_c^T r (6), diag (6) per camera and the cost, at `cams`
+    // J_c^T J_c (upper triangle, 21: its diagonal is diag(U)) and g_c = J_c^T r (6) per camera, and the cost, at `cams`
     auto linearise = [&]() -> real {
         real cost_acc = real(0);
         for (int c = wave; c < Nc; c += kWaves) {
             const CamData cam = cams[c];
-            real a[33];
+            real a[27];
 #pragma unroll
-            for (int v = 0; v < 33; v++) a[v] = real(0);
-            for (int k = cam_ptr[c] + lane; k < cam_ptr[c + 1]; k += 64) {
-                const int j = cpt[k];
-                const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
-                const double2 uv = *reinterpret_cast<const double2 *>(cuv + 2 * (int64_t)k);
-                ObsLin o;
-                project_obs(cam, P, uv.x, uv.y, K, o);
-                real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
-                if (c == hub.cam && j == hub.pt) {
-                    const real w = huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);
-                    scale_lin(o, w);
+            for (int v = 0; v < 27; v++) a[v] = real(0);
+            const int kend = cam_ptr[c + 1];
+            for (int k0 = cam_ptr[c] + lane; k0 < kend; k0 += 64 * kBatch) {
+                Obs ob[kBatch];
+                fetch_batch(k0, kend, ob);
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    if (ob[u].j < 0) continue;
+                    ObsLin o;
+                    project_obs(cam, ob[u].P, ob[u].uv.x, ob[u].uv.y, K, o);
+                    real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
+                    if (c == hub.cam && ob[u].j == hub.pt) {
+                        const real w = huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);
+                        scale_lin(o, w);
+                    }
+                    cost_acc += hr;
+                    real Jc[12];
+                    camera_jac(cam, o, ob[u].P, Jc);
+                    int idx = 0;
+#pragma unroll
+                    for (int p = 0; p < 6; p++) {
+#pragma unroll
+                        for (int q = p; q < 6; q++) { a[idx] = fma(Jc[p], Jc[q], fma(Jc[6 + p], Jc[6 + q], a[idx])); idx++; }
+                        a[21 + p] = fma(Jc[p], o.r0, fma(Jc[6 + p], o.r1, a[21 + p]));
+                    }
                 }
-                cost_acc += hr;
-                real Jc[12];
-                camera_jac(cam, o, P, Jc);
+            }
+            wave_sum_all<27>(a);
+            if (lane == 0) {
                 int idx = 0;
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
+                    U[6 * c + p] = a[idx];
 #pragma unroll
-                    for (int q = p; q < 6; q++) { a[idx] = fma(Jc[p], Jc[q], fma(Jc[6 + p], Jc[6 + q], a[idx])); idx++; }
-                    a[21 + p] = fma(Jc[p], o.r0, fma(Jc[6 + p], o.r1, a[21 + p]));
-                    a[27 + p] = fma(Jc[p], Jc[p], fma(Jc[6 + p], Jc[6 + p], a[27 + p]));
+                    for (int q = p; q < 6; q++) { S[c][idx] = a[idx]; idx++; }
+                    gc[6 * c + p] = a[21 + p];
                 }
-            }
-            wave_sum_all<33>(a);
-            if (lane == 0) {
-#pragma unroll
-                for (int v = 0; v < 21; v++) S[c][v] = a[v];
-#pragma unroll
-                for (int p = 0; p < 6; p++) { gc[6 * c + p] = a[21 + p]; U[6 * c + p] = a[27 + p]; }
             }
         }
         return block_sum_all(cost_acc, scratch);

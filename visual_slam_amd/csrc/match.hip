@@ -380,11 +380,11 @@ dot_top2_kernel(const _Float16 *__restrict__ a16, const _Float16 *__restrict__ b
         const int s = (tc - c_begin) * kStepsPerTile + kt;
         // Wait until this wave's share of stage s has landed; after the barrier every wave's has,
         // and every wave has finished reading ring slot (s - 1) % kRing, which is refilled next.
-        // Loads return in issue order, so allowing the DMAs of the kRing - 2 younger stages to
-        // stay in flight retires stage s; the first step of a tile (the epilogue's stores sit
-        // between the DMAs, and loads and stores do not retire in order relative to each other:
-        // a counted wait with stores pending could let a DMA piece slip) and the tail of the band
-        // (fewer younger stages exist) drain fully.
+        // Vector-memory operations retire in issue order, so allowing the DMAs of the kRing - 2
+        // younger stages to stay in flight retires stage s; the first step of a tile (the
+        // epilogue's two stores follow the DMAs; letting them stay in flight with a counted wait
+        // was measured and gains nothing) and the tail of the band (fewer younger stages exist)
+        // drain fully.
         if (kt == 0 || s + kRing - 2 >= n_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInflight) : "memory");
         __builtin_amdgcn_s_barrier();

@@ -48,7 +48,7 @@ def test_device_build_equals_host_build(monkeypatch, case, kw):
         p.linearize(dc, dp)
         br, bc, S, rhs, cost = p.reduced_system()
         Vinv6, gp = p.landmark_blocks()
-        res, Jc, Jp, ecost = p.evaluate()
+        ecost, res, Jc, Jp = p.evaluate()
         step = None
         if "world" not in kw:
             step = p.lm_step(1e4)

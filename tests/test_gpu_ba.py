@@ -412,3 +412,56 @@ def test_one_launch_motion_only_solver_equals_the_general_path(orc, monkeypatch,
     df, _, mf = fast.lm_step(1e3)
     ds, _, ms = slow.lm_step(1e3)
     assert rel(df, ds) < 1e-7 and abs(mf - ms) < 1e-7 * abs(ms)
+
+
+@pytest.mark.parametrize("shape", [(10, 500, 6, 31), (16, 400, 5, 32), (3, 60, 3, 33), (12, 300, 4, 34)])
+def test_small_window_reduced_solve_equals_the_general_solver(orc, monkeypatch, shape):
+    """Full BA of a small window (the reference's Tracking::solvePoints, src/core/tracking.cc:122-163)
+    takes its LM step through one fused launch (damping, assembly, L D L^T, solve, gradient test);
+    the same step and the same solve through the general kernels and through the oracle."""
+    Nc, Np, k, seed = shape
+    sc = synth.make_ba_scene(Nc, Np, k, band=Nc, seed=seed)
+    ref, fast = both(orc, sc)
+    slow = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    df, pf, mf = fast.lm_step(1e4)
+    monkeypatch.setenv("VS_BA_NO_SMALL_SOLVER", "1")
+    ds, ps, ms = slow.lm_step(1e4)
+    monkeypatch.delenv("VS_BA_NO_SMALL_SOLVER")
+    rc, d0, p0, m0, _, _ = ref.lm_step(1e4)
+    assert rc == 0
+    assert rel(df, ds) < 1e-8 and rel(pf, ps) < 1e-8 and abs(mf - ms) < 1e-9 * abs(ms)
+    assert rel(df, d0) < 1e-6 and rel(pf, p0) < 1e-6 and abs(mf - m0) < 1e-8 * abs(m0)
+    # the damped system left in the reduce buffer is the one the general path leaves
+    Sf, rf, _ = fast.reduced_system_dense(); Ss, rs, _ = slow.reduced_system_dense()
+    assert np.array_equal(Sf, Ss) and np.array_equal(rf, rs)
+    fast.set_cameras(sc.t0, sc.rpy0); fast.set_points(sc.pts0)
+    slow.set_cameras(sc.t0, sc.rpy0); slow.set_points(sc.pts0)
+    out_f = fast.solve()
+    monkeypatch.setenv("VS_BA_NO_SMALL_SOLVER", "1")
+    out_s = slow.solve()
+    monkeypatch.delenv("VS_BA_NO_SMALL_SOLVER")
+    out_r = ref.solve()
+    for key in ("termination", "iterations", "successful_steps"):
+        assert out_f[key] == out_s[key] == out_r[key], key
+    assert abs(out_f["final_cost"] - out_s["final_cost"]) < 1e-9 * out_s["final_cost"]
+    assert abs(out_f["final_cost"] - out_r["final_cost"]) < 1e-8 * out_r["final_cost"]
+    # nothing fixes the gauge of a full BA (src/core/optimizer.cc:90-100 is commented out), so rounding
+    # differences drift along it over the iterations: the cost agrees far better than the points
+    assert rel(fast.points(), slow.points()) < 1e-4
+
+
+def test_small_window_solve_reports_an_indefinite_system(monkeypatch):
+    """A negative LM diagonal makes the damped system indefinite: the fused solve flags every step
+    invalid as the general solver does, and the loop gives up at the fifth."""
+    sc = synth.make_ba_scene(6, 80, 3, band=6, seed=41)
+    out = {}
+    for how in ("fast", "slow"):
+        if how == "slow":
+            monkeypatch.setenv("VS_BA_NO_SMALL_SOLVER", "1")
+        p = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+        out[how] = p.solve(min_lm_diagonal=-1e30, max_lm_diagonal=-1e30)
+        p.close()
+        if how == "slow":
+            monkeypatch.delenv("VS_BA_NO_SMALL_SOLVER")
+    for how in ("fast", "slow"):
+        assert out[how]["termination"] == 2 and out[how]["iterations"] == 5 and out[how]["successful_steps"] == 0

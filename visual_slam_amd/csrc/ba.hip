@@ -91,6 +91,7 @@ struct vs_ba {
     int rank = 0, world = 1;
     HuberObs hub{ -1, -1, -1, 0.0 };
     int max_pair_gap = 0;   // largest |a - b| over the camera pairs of the reduced system
+    bool step_has_gmax = false;          // the last LM step's fused solve also wrote max |gradient|
     int nb_off = 0, n_diag_items = 0, n_off_items = 0, n_lm_blocks = 0, n_lm4_blocks = 0, item_waves = 4;
     bool stage_cams = false;
     int lds_cam_grid = 0;                 // > 0: landmark_lds_kernel (every camera in LDS, one workgroup per CU) with this grid
@@ -1122,6 +1123,25 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         VS_TRY(exchange_reduced(h));
     }
     h->prelin = false;   // the camera damping below changes the reduce buffer in place
+    // a window of a few cameras: the gradient test of the point this linearisation belongs to
+    // (scalars[4]), the damping and the dense matrix in one launch instead of five
+    const bool small_solve = !h->fix_points && h->nb_off > 0 && 6 * Nc <= kSmallSolveN && h->Np <= kSmallPrepMaxPoints &&
+                             getenv("VS_BA_NO_SMALL_SOLVER") == nullptr;
+    h->step_has_gmax = small_solve && h->world == 1;
+    if (small_solve) {
+        const int n = 6 * Nc;
+        const int ld = (n + 15) / 16 * 16;
+        const size_t elems = (size_t)n * ld;
+        if (h->dense.n < elems + kNB) VS_TRY(h->dense.alloc(elems + kNB));
+        const size_t linv_elems = (size_t)div_up(n, kNB) * kNB * kNB;
+        if (h->linv.n < linv_elems) VS_TRY(h->linv.alloc(linv_elems));
+        hipLaunchKernelGGL(small_prepare_kernel, dim3(1), dim3(kSmallSolveThreads), 0, s, Nc, h->nb_off, h->brow.p,
+                           h->bcol.p, h->S_diag(), h->S_off(), h->rhs(), h->udiag(), h->scale_c.p, (real)radius, (real)min_d,
+                           (real)max_d, h->lam_c.p, h->dcam.p, h->info.p, h->dense.p, ld, (int)(elems + kNB), h->gc(), Np,
+                           h->lmrec.p, h->step_has_gmax ? h->scalars.p + 4 : (real *)nullptr);
+        VS_TRY(launch_check("small_prepare_kernel"));
+        VS_TRY(cholesky_solve(h->dense.p, h->dcam.p, n, ld, n, h->info.p, h->linv.p, s));
+    } else {
     hipLaunchKernelGGL(camera_damping_kernel, dim3(div_up(6 * Nc, 256)), dim3(256), 0, s, Nc, h->udiag(),
                        h->scale_c.p, (const real *)nullptr, (real)radius, (real)min_d, (real)max_d, h->lam_c.p, h->S_diag(),
                        h->rhs(), h->dcam.p, h->info.p);
@@ -1170,6 +1190,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         VS_TRY(cholesky_solve(A, h->dcam.p, n, ld, bw, h->info.p, h->linv.p, s));
         }
     }
+    }
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
         hipLaunchKernelGGL(backsub_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
@@ -1216,6 +1237,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
     VS_HIP(hipMemcpyAsync(host8, h->scalars.p, 8 * sizeof(real), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
     sc->mcc = host8[0]; sc->xnorm2 = host8[1]; sc->snorm2 = host8[2]; sc->cost_new = host8[3];
+    if (h->step_has_gmax) h->host_scalars.p[8] = host8[4];
     *numeric_fail = host8[6] != 0.0;
     return VS_OK;
 }
@@ -1681,11 +1703,14 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
             // The gradient test of an accepted point is not waited for: its result arrives with the
             // scalars of the next step, and a step taken from a point that had already converged is
             // dropped (one host synchronisation per iteration instead of two).
-            bool gmax_pending = false;
+            bool gmax_pending = false, gmax_enqueued = false;
+            const bool small_window = !h->fix_points && h->nb_off > 0 && 6 * h->Nc <= kSmallSolveN && h->world == 1 &&
+                                      h->Np <= kSmallPrepMaxPoints && getenv("VS_BA_NO_SMALL_SOLVER") == nullptr;
             while (true) {
                 if (it >= o.max_num_iterations || radius < o.min_trust_region_radius) {
                     term = it >= o.max_num_iterations ? 1 : 0;
                     if (gmax_pending) {
+                        if (!gmax_enqueued) VS_TRY(gradient_max_enqueue(h));
                         VS_HIP(hipStreamSynchronize(s));
                         if (h->host_scalars.p[8] <= o.gradient_tolerance) term = 0;
                     }
@@ -1725,7 +1750,9 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
                     VS_TRY(exchange_reduced(h));
                     h->prelin = true;
                     h->prelin_radius = radius;
-                    VS_TRY(gradient_max_enqueue(h));
+                    // (a small window's next step computes the gradient test itself)
+                    gmax_enqueued = !small_window;
+                    if (gmax_enqueued) VS_TRY(gradient_max_enqueue(h));
                     gmax_pending = true;
                 } else {
                     radius /= decrease_factor;

@@ -324,4 +324,90 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Set-up of the reduced camera solve of a small window (6 Nc <= kSmallSolveN) in ONE launch of one
+// workgroup: what gradient_max_kernel + max_of_kernel, camera_damping_kernel, the clearing of the
+// dense matrix and assemble_lower_kernel do in five launches for a system of any size.  At ten
+// keyframes (the reference's tracking window, src/core/tracking.cc:597-601) those launches cost
+// several times the work in them.
+//   1. (gmax_out != nullptr) max |gradient| of the linearisation the system belongs to
+//   2. LM diagonal of the cameras, added to S_cc in place; right-hand side copied into the solution
+//      vector; status word cleared (as camera_damping_kernel does)
+//   3. the dense lower triangle A[i * ld + k] (k <= i) for cholesky_solve, the rest of the buffer
+//      (a_elems reals) zero
+// (A factorisation inside this kernel was built and measured: one workgroup, L D L^T with the
+// elements in registers, one barrier per column -- 1.05 us per column, 65 us at 60 unknowns,
+// against 27 us for the panel kernels of dense_solve.h; see tools/micro/small_solve_time.hip.)
+constexpr int kSmallSolveN = 90;            // 15 cameras: below the size at which the general path may choose band storage
+constexpr int kSmallPrepMaxPoints = 16384;  // landmark gradients scanned by one workgroup
+constexpr int kSmallSolveThreads = 256;
+
+__global__ void __launch_bounds__(kSmallSolveThreads)
+small_prepare_kernel(int Nc, int nb_off, const int *__restrict__ brow, const int *__restrict__ bcol,
+                     real *__restrict__ S_diag, const real *__restrict__ S_off, const real *__restrict__ rhs,
+                     const real *__restrict__ udiag, const real *__restrict__ scale_c, real radius, real min_d,
+                     real max_d, real *__restrict__ lam_out, real *__restrict__ rhs_copy, int *__restrict__ info,
+                     real *__restrict__ A, int ld, int a_elems, const real *__restrict__ gc, int np,
+                     const real *__restrict__ lmrec, real *__restrict__ gmax_out)
+{
+    __shared__ real red[kSmallSolveThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = 6 * Nc;
+    if (gmax_out) {
+        real m = 0;
+        for (int i = tid; i < n; i += kSmallSolveThreads) m = fmax(m, fabs(gc[i]));
+        for (int j = tid; j < np; j += kSmallSolveThreads) {
+            const real *g = lmrec + (int64_t)j * kRec + 9;
+            m = fmax(fmax(m, fabs(g[0])), fmax(fabs(g[1]), fabs(g[2])));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+        if (lane == 0) red[wave] = m;
+    }
+    // every element of the buffer is written exactly once: block elements by the loops below, the
+    // rest (upper triangle, padding) with zero here
+    for (int i = tid; i < a_elems; i += kSmallSolveThreads) {
+        const int r = i / ld, k = i - r * ld;
+        if (!(r < n && k <= r)) A[i] = real(0);
+    }
+    if (tid == 0) *info = 0;
+    __syncthreads();
+    if (gmax_out && tid == 0) *gmax_out = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    // all blocks are present in a window this small only if every pair of cameras shares a landmark:
+    // zero the lower triangle first where a block may be missing
+    if (nb_off != Nc * (Nc - 1) / 2) {
+        for (int i = tid; i < n * ld; i += kSmallSolveThreads) {
+            const int r = i / ld, k = i - r * ld;
+            if (k <= r) A[i] = real(0);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < Nc * 36; e += kSmallSolveThreads) {
+        const int c = e / 36, p = (e % 36) / 6, q = e % 6;
+        if (q > p) continue;
+        real v = S_diag[e];
+        if (p == q) {
+            const int i = 6 * c + p;
+            real l = real(0);
+            if (scale_c) {
+                const real s = scale_c[i], s2 = s * s;
+                real x = s2 * udiag[i];
+                x = x < min_d ? min_d : x;
+                x = x > max_d ? max_d : x;
+                l = x / radius / s2;
+            }
+            if (lam_out) lam_out[i] = l;
+            v += l;
+            S_diag[e] = v;
+            rhs_copy[i] = rhs[i];
+        }
+        A[(6 * c + p) * ld + 6 * c + q] = v;
+    }
+    for (int e = tid; e < nb_off * 36; e += kSmallSolveThreads) {
+        const int blk = e / 36, p = (e % 36) / 6, q = e % 6;
+        const int a = brow[blk], b = bcol[blk];          // a < b: S_ab[p][q] is element (6 b + q, 6 a + p)
+        A[(6 * b + q) * ld + 6 * a + p] = S_off[e];
+    }
+}
+
 }  // namespace vs

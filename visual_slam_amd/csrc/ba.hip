@@ -151,6 +151,8 @@ struct vs_ba {
         cand_partial, gmax_partial, scalars, dense, linv, bcr_ws;
     DevBuf<int> info;
     PinnedBuf<real> host_scalars;   // 16 reals: [0,8) step scalars, 8 gradient maximum, 9 cost
+    PinnedBuf<unsigned long long, true> mail;   // 8 step scalars + sequence number, written by small_tail_kernel, polled by the host
+    unsigned long long mail_seq = 0;
 
     real *S_diag() { return red.p; }
     real *S_off() { return red.p + (int64_t)Nc * 36; }
@@ -259,7 +261,7 @@ int make_items(vs_ba *h, const int *cam_ptr, const int *bptr, ItemLists &out)
     const int Nc = h->Nc, Np = h->Np, nb_off = h->nb_off, No = h->No, pt_lo = h->pt_lo, pt_hi = h->pt_hi;
     const int n_ent = bptr[nb_off];
     // work items: one workgroup each; 4 waves per item and 4 entries per thread when the typical
-    // block is large, else 1 wave and 3 entries (measured optima at 50 / 1000 / 10000 cameras).  Blocks that fit one item are written by the block kernel directly,
+    // block is large, else 1 wave and 2 entries (measured optima at 50 / 1000 / 10000 cameras).  Blocks that fit one item are written by the block kernel directly,
     // the others go through partials + finalize.
     {
         int64_t nb_used = 0, nc_used = 0;
@@ -267,6 +269,9 @@ int make_items(vs_ba *h, const int *cam_ptr, const int *bptr, ItemLists &out)
         for (int k = 0; k < nb_off; k++) nb_used += bptr[k + 1] > bptr[k];
         const double avg = nb_used ? double(n_ent) / double(nb_used) : (nc_used ? double(No) / double(nc_used) : 0.0);
         h->item_waves = avg >= 512.0 ? 4 : 1;
+        // a window of a few keyframes cannot fill the chip either way; as 4-wave items every block
+        // is a single item and the finalize launch disappears, which is worth more there
+        if ((int64_t)n_ent + No <= 32768) h->item_waves = 4;
     }
     if (const char *e = getenv("VS_BA_ITEM_WAVES")) h->item_waves = atoi(e) == 4 ? 4 : 1;   // tuning knobs
     int ept = h->item_waves == 4 ? kEpt4 : kEpt1;          // entries per thread and item
@@ -1191,6 +1196,45 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
         }
     }
     }
+    // ... and the rest of the step of such a window (back-substitution, candidate, its cost, the
+    // step's sums) in one launch instead of four
+    if (small_solve && !is_sharded(h) && Np <= kSmallTailMaxPoints) {
+        const bool use_mail = getenv("VS_BA_NO_MAILBOX") == nullptr;
+        if (use_mail && !h->mail.p) {
+            VS_TRY(h->mail.alloc(16));
+            h->mail.p[8] = 0;
+            h->mail_seq = 0;
+        }
+        const unsigned long long seq = ++h->mail_seq;
+        hipLaunchKernelGGL(small_tail_kernel, dim3(1), dim3(kSmallTailThreads), 0, s, Np, Nc, h->K, h->cams.p, h->t.p, h->rpy.p,
+                           h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p, h->lmrec.p, h->dcam.p,
+                           h->cam_used.p, h->pt_used.p, h->dpt.p, h->t2.p, h->rpy2.p, h->pts2.p, (int)want_candidate_cost,
+                           h->info.p, h->scalars.p, use_mail ? h->mail.p : (unsigned long long *)nullptr, seq);
+        VS_TRY(launch_check("small_tail_kernel"));
+        if (use_mail) {
+            // poll the mailbox (a stream synchronisation costs more than the kernels of a small step);
+            // should the number not arrive the stream is synchronised, which also surfaces a fault
+            const auto t_start = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            bool arrived = true;
+            while (__atomic_load_n(h->mail.p + 8, __ATOMIC_ACQUIRE) != seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 4095u) == 0 &&
+                    std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) { arrived = false; break; }
+            }
+            if (!arrived) {
+                VS_HIP(hipStreamSynchronize(s));
+                VS_CHECK(__atomic_load_n(h->mail.p + 8, __ATOMIC_ACQUIRE) == seq, VS_ERR_HIP,
+                         "the LM step's result did not reach host memory");
+            }
+            h->busy[0] = h->busy[1] = h->busy[2] = false;    // everything enqueued before the kernel has finished
+            const real *m = reinterpret_cast<const real *>(h->mail.p);
+            sc->mcc = m[0]; sc->xnorm2 = m[1]; sc->snorm2 = m[2]; sc->cost_new = m[3];
+            *numeric_fail = m[6] != 0.0;
+            if (h->step_has_gmax) h->host_scalars.p[8] = m[4];
+            return VS_OK;
+        }
+    } else {
     const size_t lds = cam_lds_bytes(h);
     if (h->stage_cams)
         hipLaunchKernelGGL(backsub_kernel<true>, dim3(h->n_lm_blocks), dim3(kLmThreads), lds, s, Np, Nc, h->K,
@@ -1232,6 +1276,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
                        h->cand_partial.p, want_candidate_cost ? h->n_lm_blocks : 0, h->ccost_partial.p, h->info.p,
                        h->scalars.p);
     VS_TRY(launch_check("step_scalars_kernel"));
+    }
     real *host8 = h->host_scalars.p;
     VS_TRY(cross_gpu_sum(h, h->scalars.p, 4));
     VS_HIP(hipMemcpyAsync(host8, h->scalars.p, 8 * sizeof(real), hipMemcpyDeviceToHost, s));

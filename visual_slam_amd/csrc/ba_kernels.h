@@ -1202,7 +1202,7 @@ __device__ __forceinline__ real backsub_landmark(int j, int b, int e, const real
                                                  const int *__restrict__ lcam, const real *__restrict__ luv,
                                                  const HuberObs &hub, const real *__restrict__ hub_w, int fix_points,
                                                  const real *__restrict__ lmrec, const real *__restrict__ dcam,
-                                                 real *__restrict__ dpt, CamFetch fetch)
+                                                 real *__restrict__ dpt, CamFetch fetch, real *dp_out = nullptr)
 {
     real dp[3] = { 0, 0, 0 };
     real mcc = real(0);
@@ -1258,6 +1258,7 @@ __device__ __forceinline__ real backsub_landmark(int j, int b, int e, const real
         mcc = -((s_ur + dp_g) + real(0.5) * (s_uu + real(2) * dp_q + dp_V_dp));
     }
     dpt[3 * j] = dp[0]; dpt[3 * j + 1] = dp[1]; dpt[3 * j + 2] = dp[2];
+    if (dp_out) { dp_out[0] = dp[0]; dp_out[1] = dp[1]; dp_out[2] = dp[2]; }
     return mcc;
 }
 

@@ -410,4 +410,113 @@ small_prepare_kernel(int Nc, int nb_off, const int *__restrict__ brow, const int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The rest of an LM step of a small window in ONE launch of one workgroup: what backsub_kernel,
+// candidate_kernel, cost_kernel and step_scalars_kernel do in four.  A thread takes a landmark
+// through all of it -- back-substitution (step of the point, its share of the model cost change),
+// candidate position, cost of its observations at the candidate -- because nothing in that chain
+// needs another landmark; the candidate cameras are built into LDS first.  The four sums of the
+// step (model cost change, |x|^2, |d|^2, candidate cost) are added in a fixed order.  With `mail`
+// the step's scalars also go straight into host memory, followed by the sequence number `seq`: the
+// host polls for it instead of paying a copy and a stream synchronisation per LM iteration.
+constexpr int kSmallTailThreads = 1024;
+constexpr int kSmallTailMaxPoints = 8192;
+
+__device__ __forceinline__ real block_sum_tail(real v, real *scratch /* >= 16 reals */)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    real s = real(0);
+    if (threadIdx.x == 0)
+        for (int i = 0; i < kSmallTailThreads / 64; i++) s += scratch[i];
+    return s;
+}
+
+__global__ void __launch_bounds__(kSmallTailThreads)
+small_tail_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, const real *__restrict__ t,
+                  const real *__restrict__ rpy, const real *__restrict__ pts, const int *__restrict__ pt_ptr,
+                  const int *__restrict__ lcam, const real *__restrict__ luv, HuberObs hub, const real *__restrict__ hub_w,
+                  const real *__restrict__ lmrec, const real *__restrict__ dcam, const unsigned char *__restrict__ cam_used,
+                  const unsigned char *__restrict__ pt_used, real *__restrict__ dpt, real *__restrict__ t2,
+                  real *__restrict__ rpy2, real *__restrict__ pts2, int want_cost, const int *__restrict__ info,
+                  real *__restrict__ out, unsigned long long *mail, unsigned long long seq)
+{
+    __shared__ CamData scams[kSmallSolveN / 6], scams2[kSmallSolveN / 6];
+    __shared__ real x2[kSmallSolveN], red[kSmallTailThreads / 64];
+    const int tid = threadIdx.x;
+    real xn = 0, dn = 0, mcc = 0, cost = 0;
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(cams);
+        double2 *dst = reinterpret_cast<double2 *>(scams);
+        for (int i = tid; i < Nc * 8; i += kSmallTailThreads) dst[i] = src[i];
+    }
+    if (tid < 6 * Nc) {
+        const int c = tid / 6, k = tid % 6;
+        const bool used = cam_used[c] != 0;
+        const real x = k < 3 ? t[3 * c + k] : rpy[3 * c + k - 3];
+        const real d = used ? dcam[tid] : real(0);
+        x2[tid] = x + d;
+        if (k < 3) t2[3 * c + k] = x + d; else rpy2[3 * c + k - 3] = x + d;
+        if (used) { xn = x * x; dn = d * d; }
+    }
+    __syncthreads();
+    if (tid < Nc) {
+        real sr, cr, sp, cp, sy, cy;
+        sincos(x2[6 * tid + 3], &sr, &cr);
+        sincos(x2[6 * tid + 4], &sp, &cp);
+        sincos(x2[6 * tid + 5], &sy, &cy);
+        // cam_from_sincos reads the translation as t[3 c + k]
+        const real tt[3] = { x2[6 * tid], x2[6 * tid + 1], x2[6 * tid + 2] };
+        scams2[tid] = cam_from_sincos(tt, 0, sr, cr, sp, cp, sy, cy);
+    }
+    __syncthreads();
+    for (int j = tid; j < Np; j += kSmallTailThreads) {
+        const int b = pt_ptr[j], e = pt_ptr[j + 1];
+        const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
+        real dp[3];
+        mcc += backsub_landmark(j, b, e, P, K, lcam, luv, hub, hub_w, 0, lmrec, dcam, dpt,
+                                [&](int c, CamData &cd) { cd = scams[c]; }, dp);
+        const bool used = pt_used[j] != 0;
+        real P2[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const real d = used ? dp[k] : real(0);
+            P2[k] = P[k] + d;
+            pts2[3 * j + k] = P2[k];
+            if (used) { xn += P[k] * P[k]; dn += d * d; }
+        }
+        if (want_cost)
+            for (int pos = b; pos < e; pos++) {
+                const CamData cd = scams2[lcam[pos]];
+                ObsLin o;
+                project_obs(cd, P2, luv[2 * pos], luv[2 * pos + 1], K, o);
+                real hr = real(0.5) * (o.r0 * o.r0 + o.r1 * o.r1);
+                if (pos == hub.pos) (void)huber_weight(hub.a, o.r0 * o.r0 + o.r1 * o.r1, &hr);
+                cost += hr;
+            }
+    }
+    mcc = block_sum_tail(mcc, red);
+    xn = block_sum_tail(xn, red);
+    dn = block_sum_tail(dn, red);
+    cost = block_sum_tail(cost, red);
+    if (tid == 0) {
+        out[0] = mcc; out[1] = xn; out[2] = dn;
+        if (want_cost) out[3] = cost;
+        out[6] = (real)*info;
+        if (mail) {
+            // the eight scalars of the step straight into the host's (coherent, page-locked) mailbox,
+            // then the sequence number the host is polling for
+            real *m = reinterpret_cast<real *>(mail);
+            m[0] = mcc; m[1] = xn; m[2] = dn; m[3] = want_cost ? cost : out[3];
+            m[4] = out[4]; m[5] = out[5]; m[6] = (real)*info; m[7] = out[7];
+            __threadfence_system();
+            __hip_atomic_store(mail + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 }  // namespace vs

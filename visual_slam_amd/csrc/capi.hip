@@ -29,11 +29,11 @@ struct Pool {
     std::vector<void *> free_list[kPoolDevices][kPoolClasses];
     size_t kept[kPoolDevices] = {};
 };
-// 0: device memory, 1: page-locked host memory.  Never destroyed: buffers may be let go of while
-// the process winds down.
+// 0: device memory, 1: page-locked host memory, 2: page-locked coherent host memory.  Never
+// destroyed: buffers may be let go of while the process winds down.
 Pool *pools()
 {
-    static Pool *p = new Pool[2];
+    static Pool *p = new Pool[3];
     return p;
 }
 
@@ -47,14 +47,15 @@ int pool_class(size_t bytes)
 }  // namespace
 
 // In a destructor that runs at process exit the runtime may already be gone: errors are ignored.
-void *pool_alloc(size_t bytes, bool host, int *status, int *device)
+void *pool_alloc(size_t bytes, int kind, int *status, int *device)
 {
     *status = VS_OK;
     if (bytes == 0) bytes = 1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kPoolDevices) dev = -1;
     *device = dev;
-    Pool &pl = pools()[host ? 1 : 0];
+    const bool host = kind != 0;
+    Pool &pl = pools()[kind];
     size_t want = bytes;
     if (dev >= 0 && bytes <= kPoolMaxBlock) {
         const int c = pool_class(bytes);
@@ -69,7 +70,9 @@ void *pool_alloc(size_t bytes, bool host, int *status, int *device)
         }
     }
     void *p = nullptr;
-    const hipError_t e = host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    const hipError_t e = kind == 2   ? hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped)
+                         : kind == 1 ? hipHostMalloc(&p, want, hipHostMallocDefault)
+                                     : hipMalloc(&p, want);
     if (e != hipSuccess) {
         set_error("%s(%zu bytes) failed: %s", host ? "hipHostMalloc" : "hipMalloc", want, hipGetErrorString(e));
         *status = e == hipErrorOutOfMemory ? VS_ERR_NOMEM : VS_ERR_HIP;
@@ -78,11 +81,12 @@ void *pool_alloc(size_t bytes, bool host, int *status, int *device)
     return p;
 }
 
-void pool_free(void *p, size_t bytes, bool host, int dev)
+void pool_free(void *p, size_t bytes, int kind, int dev)
 {
     if (!p) return;
     if (bytes == 0) bytes = 1;
-    Pool &pl = pools()[host ? 1 : 0];
+    const bool host = kind != 0;
+    Pool &pl = pools()[kind];
     if (dev >= 0 && bytes <= kPoolMaxBlock) {
         const int c = pool_class(bytes);
         const size_t sz = kPoolMinBlock << c;

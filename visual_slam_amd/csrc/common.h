@@ -38,8 +38,10 @@ void set_error(const char *fmt, ...);
 // Blocks from the process-wide pool (capi.hip): device memory, or page-locked host memory.  A block
 // belongs to the device that was current at pool_alloc (*device; -1: not pooled); `bytes` and
 // `device` at pool_free are those of pool_alloc.
-void *pool_alloc(size_t bytes, bool host, int *status, int *device);
-void pool_free(void *p, size_t bytes, bool host, int device);
+// kind: 0 device memory, 1 page-locked host memory, 2 page-locked host memory that is coherent
+// between host and GPU while a kernel runs (a kernel's stores become visible to a polling host).
+void *pool_alloc(size_t bytes, int kind, int *status, int *device);
+void pool_free(void *p, size_t bytes, int kind, int device);
 
 // Owning device buffer; returned to the pool on destruction or reset.  The owner makes sure no
 // work that uses the buffer is still running when it lets go of it: handles synchronise their
@@ -56,7 +58,7 @@ struct DevBuf {
     bool is_view = false;    // points into another buffer (see view()): nothing to give back
     void release()
     {
-        if (p && !is_view) pool_free(p, n * sizeof(T), false, dev);
+        if (p && !is_view) pool_free(p, n * sizeof(T), 0, dev);
         p = nullptr;
         n = 0;
         is_view = false;
@@ -77,7 +79,7 @@ struct DevBuf {
         reset();
         if (count == 0) count = 1;
         int rc = VS_OK;
-        p = (T *)pool_alloc(count * sizeof(T), false, &rc, &dev);
+        p = (T *)pool_alloc(count * sizeof(T), 0, &rc, &dev);
         if (rc != VS_OK) { p = nullptr; return rc; }
         n = count;
         return VS_OK;
@@ -92,21 +94,22 @@ struct DevBuf {
 
 // Owning page-locked host buffer: the target of the small device-to-host copies inside a solve (a
 // copy into pageable memory is staged by the runtime and costs several times as much).
-template <typename T>
+template <typename T, bool COHERENT = false>
 struct PinnedBuf {
+    static constexpr int kKind = COHERENT ? 2 : 1;
     T *p = nullptr;
     size_t n = 0;
     int dev = -1;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
     PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() { if (p) pool_free(p, n * sizeof(T), true, dev); }
+    ~PinnedBuf() { if (p) pool_free(p, n * sizeof(T), kKind, dev); }
     int alloc(size_t count)
     {
-        if (p) pool_free(p, n * sizeof(T), true, dev);
+        if (p) pool_free(p, n * sizeof(T), kKind, dev);
         p = nullptr; n = 0;
         int rc = VS_OK;
-        p = (T *)pool_alloc(count * sizeof(T), true, &rc, &dev);
+        p = (T *)pool_alloc(count * sizeof(T), kKind, &rc, &dev);
         if (rc != VS_OK) { p = nullptr; return rc; }
         n = count;
         return VS_OK;

@@ -123,8 +123,9 @@ struct vs_ba {
     // Small parameter uploads pass through page-locked staging owned by the handle, so the setters
     // need not wait for the copy: [t | rpy | points].  busy[r]: a copy out of region r may still be
     // in flight (r = 0 cameras, 1 points, 2 the arena staging).
-    DevBuf<SmallOut> small_out;              // motion_only_solve_kernel's summary
-    PinnedBuf<SmallOut> small_host;
+    PinnedBuf<SmallOut, true> small_host;    // motion_only_solve_kernel's summary, written by the kernel, polled by the host
+    int small_seq = 0;
+    bool init_has_gmax = false;              // the first pass of the solve left max |gradient| in scalars[4]
     PinnedBuf<real> param_stage;
     bool busy[3] = { false, false, false };
 
@@ -1093,6 +1094,27 @@ int cross_gpu_max(vs_ba *h, real *val)
 
 struct StepScalars { real mcc, xnorm2, snorm2, cost_new; };
 
+// Waits until *word == want: the last kernel of the stream writes it into coherent page-locked
+// memory after its results.  A stream synchronisation costs more than the kernels of a small
+// window's LM step; should the value not arrive within two seconds the stream is synchronised,
+// which also surfaces a fault.
+template <typename T>
+int wait_for_word(vs_ba *h, const T *word, T want)
+{
+    const auto t_start = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) {
+        __builtin_ia32_pause();
+        if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) {
+            VS_HIP(hipStreamSynchronize(h->stream));
+            VS_CHECK(__atomic_load_n(word, __ATOMIC_ACQUIRE) == want, VS_ERR_HIP, "a kernel's result did not reach host memory");
+            break;
+        }
+    }
+    h->busy[0] = h->busy[1] = h->busy[2] = false;    // everything enqueued before that kernel has finished
+    return VS_OK;
+}
+
 // Undamped pass at the handle's parameters with the Schur terms left out (only the cost, the
 // gradient, diag(U) and diag(V) are wanted), and the Jacobi scaling taken from it: the scaling of a
 // whole solve comes from the Jacobian at its first iterate.
@@ -1105,9 +1127,18 @@ int unscaled_pass(vs_ba *h)
     h->fix_points = fp;
     VS_TRY(rc);
     VS_TRY(exchange_reduced(h));
+    h->init_has_gmax = false;
+    if (!is_sharded(h) && h->Np <= kSmallPrepMaxPoints && h->Nc <= kSmallPrepMaxPoints && getenv("VS_BA_NO_SMALL_SOLVER") == nullptr) {
+        // a small window: both scalings and the gradient test of this first pass in one launch
+        hipLaunchKernelGGL(small_scales_kernel, dim3(1), dim3(1024), 0, h->stream, 6 * h->Nc, h->udiag(), h->scale_c.p, h->Np,
+                           h->Vdiag.p, h->scale_p.p, h->gc(), fp ? 0 : h->Np, h->lmrec.p, h->scalars.p + 4);
+        VS_TRY(launch_check("small_scales_kernel"));
+        h->init_has_gmax = true;
+    } else {
     hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(6 * h->Nc, 256)), dim3(256), 0, h->stream, 6 * h->Nc, h->udiag(), h->scale_c.p);
     hipLaunchKernelGGL(jacobi_scale_kernel, dim3(div_up(3 * (int64_t)h->Np, 256)), dim3(256), 0, h->stream, 3 * h->Np, h->Vdiag.p, h->scale_p.p);
     VS_TRY(launch_check("jacobi_scale_kernel"));
+    }
     h->have_scale = true;
     h->prelin = false;
     return VS_OK;
@@ -1212,22 +1243,7 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
                            h->info.p, h->scalars.p, use_mail ? h->mail.p : (unsigned long long *)nullptr, seq);
         VS_TRY(launch_check("small_tail_kernel"));
         if (use_mail) {
-            // poll the mailbox (a stream synchronisation costs more than the kernels of a small step);
-            // should the number not arrive the stream is synchronised, which also surfaces a fault
-            const auto t_start = std::chrono::steady_clock::now();
-            unsigned spins = 0;
-            bool arrived = true;
-            while (__atomic_load_n(h->mail.p + 8, __ATOMIC_ACQUIRE) != seq) {
-                __builtin_ia32_pause();
-                if ((++spins & 4095u) == 0 &&
-                    std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) { arrived = false; break; }
-            }
-            if (!arrived) {
-                VS_HIP(hipStreamSynchronize(s));
-                VS_CHECK(__atomic_load_n(h->mail.p + 8, __ATOMIC_ACQUIRE) == seq, VS_ERR_HIP,
-                         "the LM step's result did not reach host memory");
-            }
-            h->busy[0] = h->busy[1] = h->busy[2] = false;    // everything enqueued before the kernel has finished
+            VS_TRY(wait_for_word(h, h->mail.p + 8, seq));
             const real *m = reinterpret_cast<const real *>(h->mail.p);
             sc->mcc = m[0]; sc->xnorm2 = m[1]; sc->snorm2 = m[2]; sc->cost_new = m[3];
             *numeric_fail = m[6] != 0.0;
@@ -1714,14 +1730,20 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
     // Motion-only BA of a small window (the reference's live mode): the whole loop in one launch
     if (h->fix_points && h->world == 1 && h->Nc <= kSmallMaxCams && h->No > 0 && h->No <= kSmallMaxObs &&
         getenv("VS_BA_NO_SMALL_SOLVER") == nullptr) {
-        if (!h->small_out.p) VS_TRY(h->small_out.alloc(1));
-        if (!h->small_host.p) VS_TRY(h->small_host.alloc(1));
+        if (!h->small_host.p) {
+            VS_TRY(h->small_host.alloc(1));
+            h->small_host.p->seq = 0;
+            h->small_seq = 0;
+        }
+        const int seq = ++h->small_seq;
         hipLaunchKernelGGL(motion_only_solve_kernel, dim3(1), dim3(kSmallThreads), 0, s, h->Nc, h->K, h->t.p, h->rpy.p,
-                           h->pts.p, h->cam_ptr.p, h->cpt.p, h->cuv.p, h->cam_used.p, h->hub, o, h->scale_c.p, h->small_out.p);
+                           h->pts.p, h->cam_ptr.p, h->cpt.p, h->cuv.p, h->cam_used.p, h->hub, o, h->scale_c.p, h->small_host.p, seq);
         VS_TRY(launch_check("motion_only_solve_kernel"));
-        VS_HIP(hipMemcpyAsync(h->small_host.p, h->small_out.p, sizeof(SmallOut), hipMemcpyDeviceToHost, s));
-        VS_HIP(hipStreamSynchronize(s));
-        h->busy[0] = h->busy[1] = h->busy[2] = false;
+        if (getenv("VS_BA_NO_MAILBOX") == nullptr) VS_TRY(wait_for_word(h, &h->small_host.p->seq, seq));
+        else {
+            VS_HIP(hipStreamSynchronize(s));
+            h->busy[0] = h->busy[1] = h->busy[2] = false;
+        }
         h->linearized = false; h->prelin = false; h->have_scale = true;
         if (summary) {
             const SmallOut &q = *h->small_host.p;
@@ -1737,12 +1759,17 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
     // initial cost and gradient (unscaled, undamped); the same pass gives the Jacobi scaling
     VS_TRY(unscaled_pass(h));
     VS_HIP(hipMemcpyAsync(h->host_scalars.p + 9, h->cost(), sizeof(real), hipMemcpyDeviceToHost, s));
+    // the gradient test of the starting point rides on the same synchronisation
+    if (h->No_global != 0) {
+        if (h->init_has_gmax)
+            VS_HIP(hipMemcpyAsync(h->host_scalars.p + 8, h->scalars.p + 4, sizeof(real), hipMemcpyDeviceToHost, s));
+        else VS_TRY(gradient_max_enqueue(h));
+    }
     VS_HIP(hipStreamSynchronize(s));
     cost0 = cost = h->host_scalars.p[9];
     if (h->No_global == 0) term = 0;
     else {
-        real gmax = 0;
-        VS_TRY(gradient_max(h, &gmax));
+        const real gmax = h->host_scalars.p[8];
         if (gmax <= o.gradient_tolerance) term = 0;
         else {
             // The gradient test of an accepted point is not waited for: its result arrives with the

@@ -17,9 +17,9 @@ constexpr int kSmallThreads = 512;     // two waves per SIMD: 256 registers per 
 constexpr int kSmallMaxCams = 128;
 constexpr int kSmallMaxObs = 16384;
 
-struct SmallOut {            // written by thread 0
-    real initial_cost, final_cost, final_radius;
-    int iterations, successful_steps, termination, pad;
+struct SmallOut {            // written by thread 0, straight into coherent page-locked host memory;
+    real initial_cost, final_cost, final_radius;     // `seq` last: the host polls for it
+    int iterations, successful_steps, termination, seq;
 };
 
 // sum over the wave of NV per-lane values, every lane ends with the totals (butterfly order: fixed)
@@ -52,7 +52,7 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
                          const real *__restrict__ pts, const int *__restrict__ cam_ptr,
                          const int *__restrict__ cpt, const real *__restrict__ cuv,
                          const unsigned char *__restrict__ cam_used, HuberObs hub, vs_lm_options opt,
-                         real *__restrict__ scale_out, SmallOut *__restrict__ out)
+                         real *__restrict__ scale_out, SmallOut *out, int seq)
 {
     __shared__ CamData cams[kSmallMaxCams], cams2[kSmallMaxCams];
     __shared__ real x[6 * kSmallMaxCams], x2[6 * kSmallMaxCams], scale[6 * kSmallMaxCams], dc[6 * kSmallMaxCams];
@@ -320,7 +320,13 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
     }
     if (tid == 0) {
         out->initial_cost = cost0; out->final_cost = cost; out->final_radius = radius;
-        out->iterations = it; out->successful_steps = nsucc; out->termination = term; out->pad = 0;
+        out->iterations = it; out->successful_steps = nsucc; out->termination = term;
+    }
+    // the cameras above must be in memory before the host sees the sequence number
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -411,6 +417,37 @@ small_prepare_kernel(int Nc, int nb_off, const int *__restrict__ brow, const int
 }
 
 // ---------------------------------------------------------------------------------------------
+// After the first (undamped) pass of a solve over a small window: the Jacobi scales of cameras and
+// landmarks, s = 1 / (1 + sqrt(H_ii)), and max |gradient|, in ONE launch of one workgroup instead of
+// the four of jacobi_scale_kernel (twice), gradient_max_kernel and max_of_kernel.
+__global__ void __launch_bounds__(1024)
+small_scales_kernel(int nc6, const real *__restrict__ udiag, real *__restrict__ scale_c, int np,
+                    const real *__restrict__ vdiag, real *__restrict__ scale_p, const real *__restrict__ gc,
+                    int np_grad, const real *__restrict__ lmrec, real *__restrict__ gmax_out)
+{
+    __shared__ real red[16];
+    const int tid = threadIdx.x;
+    real m = 0;
+    for (int i = tid; i < nc6; i += 1024) {
+        scale_c[i] = real(1) / (real(1) + sqrt(udiag[i]));
+        m = fmax(m, fabs(gc[i]));
+    }
+    for (int i = tid; i < 3 * np; i += 1024) scale_p[i] = real(1) / (real(1) + sqrt(vdiag[i]));
+    for (int j = tid; j < np_grad; j += 1024) {
+        const real *g = lmrec + (int64_t)j * kRec + 9;
+        m = fmax(fmax(m, fabs(g[0])), fmax(fabs(g[1]), fabs(g[2])));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) m = fmax(m, red[w]);
+        *gmax_out = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The rest of an LM step of a small window in ONE launch of one workgroup: what backsub_kernel,
 // candidate_kernel, cost_kernel and step_scalars_kernel do in four.  A thread takes a landmark
 // through all of it -- back-substitution (step of the point, its share of the model cost change),
@@ -474,23 +511,76 @@ small_tail_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, cons
         scams2[tid] = cam_from_sincos(tt, 0, sr, cr, sp, cp, sy, cy);
     }
     __syncthreads();
-    for (int j = tid; j < Np; j += kSmallTailThreads) {
+    // two lanes per landmark: each takes every other observation in both passes, the sums of the
+    // back-substitution are united with one exchange between the neighbours
+    const int sub = tid & 1;
+    for (int j = tid >> 1; j < Np; j += kSmallTailThreads / 2) {
         const int b = pt_ptr[j], e = pt_ptr[j + 1];
         const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
-        real dp[3];
-        mcc += backsub_landmark(j, b, e, P, K, lcam, luv, hub, hub_w, 0, lmrec, dcam, dpt,
-                                [&](int c, CamData &cd) { cd = scams[c]; }, dp);
+        real acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // q[3] | V[6] | sum u.r | sum u.u
+        for (int pos = b + sub; pos < e; pos += 2) {
+            const int c = lcam[pos];
+            const double2 uv = *reinterpret_cast<const double2 *>(luv + 2 * (int64_t)pos);
+            const double2 *dsrc = reinterpret_cast<const double2 *>(dcam + 6 * (int64_t)c);
+            const double2 d01 = dsrc[0], d23 = dsrc[1], d45 = dsrc[2];
+            const CamData cd = scams[c];
+            ObsLin o;
+            project_obs(cd, P, uv.x, uv.y, K, o);
+            if (pos == hub.pos) scale_lin(o, *hub_w);
+            real Jc[12], Jp[6];
+            camera_jac(cd, o, P, Jc);
+            point_jac(cd, o, Jp);
+            const real d[6] = { d01.x, d01.y, d23.x, d23.y, d45.x, d45.y };
+            real u0 = 0, u1 = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { u0 += Jc[k] * d[k]; u1 += Jc[6 + k] * d[k]; }
+            acc[9] += u0 * o.r0 + u1 * o.r1;
+            acc[10] += u0 * u0 + u1 * u1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc[k] += Jp[k] * u0 + Jp[3 + k] * u1;
+            acc[3] += Jp[0] * Jp[0] + Jp[3] * Jp[3]; acc[4] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
+            acc[5] += Jp[0] * Jp[2] + Jp[3] * Jp[5]; acc[6] += Jp[1] * Jp[1] + Jp[4] * Jp[4];
+            acc[7] += Jp[1] * Jp[2] + Jp[4] * Jp[5]; acc[8] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
+        }
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const real other = __shfl_xor(acc[k], 1, 64);
+            acc[k] = sub == 0 ? acc[k] + other : other + acc[k];     // both lanes: even lane's share first
+        }
+        const real *q = acc, *V = acc + 3;
+        real rec[kRec];
+        load_rec(lmrec, j, rec, 6);
+        const real *vi = rec + 3, *gp = rec + 9;
+        real dp[3] = { 0, 0, 0 };
+        if (e > b) {
+            const real a0 = gp[0] + q[0], a1 = gp[1] + q[1], a2 = gp[2] + q[2];
+            dp[0] = -(vi[0] * a0 + vi[1] * a1 + vi[2] * a2);
+            dp[1] = -(vi[1] * a0 + vi[3] * a1 + vi[4] * a2);
+            dp[2] = -(vi[2] * a0 + vi[4] * a1 + vi[5] * a2);
+        }
         const bool used = pt_used[j] != 0;
         real P2[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const real d = used ? dp[k] : real(0);
-            P2[k] = P[k] + d;
-            pts2[3 * j + k] = P2[k];
-            if (used) { xn += P[k] * P[k]; dn += d * d; }
+        for (int k = 0; k < 3; k++) P2[k] = P[k] + (used ? dp[k] : real(0));
+        if (sub == 0) {
+            if (e > b) {
+                const real Vd0 = V[0] * dp[0] + V[1] * dp[1] + V[2] * dp[2];
+                const real Vd1 = V[1] * dp[0] + V[3] * dp[1] + V[4] * dp[2];
+                const real Vd2 = V[2] * dp[0] + V[4] * dp[1] + V[5] * dp[2];
+                const real dp_g = dp[0] * gp[0] + dp[1] * gp[1] + dp[2] * gp[2];
+                const real dp_q = dp[0] * q[0] + dp[1] * q[1] + dp[2] * q[2];
+                const real dp_V_dp = dp[0] * Vd0 + dp[1] * Vd1 + dp[2] * Vd2;
+                mcc += -((acc[9] + dp_g) + real(0.5) * (acc[10] + real(2) * dp_q + dp_V_dp));
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                dpt[3 * j + k] = dp[k];
+                pts2[3 * j + k] = P2[k];
+                if (used) { xn += P[k] * P[k]; dn += dp[k] * dp[k]; }
+            }
         }
         if (want_cost)
-            for (int pos = b; pos < e; pos++) {
+            for (int pos = b + sub; pos < e; pos += 2) {
                 const CamData cd = scams2[lcam[pos]];
                 ObsLin o;
                 project_obs(cd, P2, luv[2 * pos], luv[2 * pos + 1], K, o);

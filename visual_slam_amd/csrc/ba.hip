@@ -154,6 +154,8 @@ struct vs_ba {
     PinnedBuf<real> host_scalars;   // 16 reals: [0,8) step scalars, 8 gradient maximum, 9 cost
     PinnedBuf<unsigned long long, true> mail;   // 8 step scalars + sequence number, written by small_tail_kernel, polled by the host
     unsigned long long mail_seq = 0;
+    DevBuf<real> tail_partial;               // small_tail_kernel: four sums per workgroup
+    DevBuf<int> tail_ticket;                 // ... and its ticket counter (zero between launches)
 
     real *S_diag() { return red.p; }
     real *S_off() { return red.p + (int64_t)Nc * 36; }
@@ -1237,10 +1239,17 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
             h->mail_seq = 0;
         }
         const unsigned long long seq = ++h->mail_seq;
-        hipLaunchKernelGGL(small_tail_kernel, dim3(1), dim3(kSmallTailThreads), 0, s, Np, Nc, h->K, h->cams.p, h->t.p, h->rpy.p,
+        const int groups = std::min(kSmallTailMaxGroups, std::max(1, div_up(Np, kSmallTailThreads / 2)));
+        if (!h->tail_ticket.p) {
+            VS_TRY(h->tail_partial.alloc(4 * kSmallTailMaxGroups));
+            VS_TRY(h->tail_ticket.alloc(1));
+            VS_HIP(hipMemsetAsync(h->tail_ticket.p, 0, sizeof(int), s));
+        }
+        hipLaunchKernelGGL(small_tail_kernel, dim3(groups), dim3(kSmallTailThreads), 0, s, Np, Nc, h->K, h->cams.p, h->t.p, h->rpy.p,
                            h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p, h->lmrec.p, h->dcam.p,
                            h->cam_used.p, h->pt_used.p, h->dpt.p, h->t2.p, h->rpy2.p, h->pts2.p, (int)want_candidate_cost,
-                           h->info.p, h->scalars.p, use_mail ? h->mail.p : (unsigned long long *)nullptr, seq);
+                           h->info.p, h->tail_partial.p, h->tail_ticket.p, h->scalars.p,
+                           use_mail ? h->mail.p : (unsigned long long *)nullptr, seq);
         VS_TRY(launch_check("small_tail_kernel"));
         if (use_mail) {
             VS_TRY(wait_for_word(h, h->mail.p + 8, seq));

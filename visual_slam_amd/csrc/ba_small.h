@@ -346,7 +346,7 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
 // against 27 us for the panel kernels of dense_solve.h; see tools/micro/small_solve_time.hip.)
 constexpr int kSmallSolveN = 90;            // 15 cameras: below the size at which the general path may choose band storage
 constexpr int kSmallPrepMaxPoints = 16384;  // landmark gradients scanned by one workgroup
-constexpr int kSmallSolveThreads = 256;
+constexpr int kSmallSolveThreads = 1024;    // the kernel is a few dependent memory round trips: more threads, fewer turns per loop
 
 __global__ void __launch_bounds__(kSmallSolveThreads)
 small_prepare_kernel(int Nc, int nb_off, const int *__restrict__ brow, const int *__restrict__ bcol,
@@ -378,7 +378,11 @@ small_prepare_kernel(int Nc, int nb_off, const int *__restrict__ brow, const int
     }
     if (tid == 0) *info = 0;
     __syncthreads();
-    if (gmax_out && tid == 0) *gmax_out = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (gmax_out && tid == 0) {
+        real m = red[0];
+        for (int w = 1; w < kSmallSolveThreads / 64; w++) m = fmax(m, red[w]);
+        *gmax_out = m;
+    }
     // all blocks are present in a window this small only if every pair of cameras shares a landmark:
     // zero the lower triangle first where a block may be missing
     if (nb_off != Nc * (Nc - 1) / 2) {
@@ -448,18 +452,21 @@ small_scales_kernel(int nc6, const real *__restrict__ udiag, real *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The rest of an LM step of a small window in ONE launch of one workgroup: what backsub_kernel,
-// candidate_kernel, cost_kernel and step_scalars_kernel do in four.  A thread takes a landmark
-// through all of it -- back-substitution (step of the point, its share of the model cost change),
-// candidate position, cost of its observations at the candidate -- because nothing in that chain
-// needs another landmark; the candidate cameras are built into LDS first.  The four sums of the
-// step (model cost change, |x|^2, |d|^2, candidate cost) are added in a fixed order.  With `mail`
-// the step's scalars also go straight into host memory, followed by the sequence number `seq`: the
-// host polls for it instead of paying a copy and a stream synchronisation per LM iteration.
-constexpr int kSmallTailThreads = 1024;
-constexpr int kSmallTailMaxPoints = 8192;
+// The rest of an LM step of a small window in ONE launch: what backsub_kernel, candidate_kernel,
+// cost_kernel and step_scalars_kernel do in four.  Two lanes take a landmark through all of it --
+// back-substitution (step of the point, its share of the model cost change), candidate position,
+// cost of its observations at the candidate -- because nothing in that chain needs another
+// landmark; every workgroup builds the candidate cameras into its LDS first.  The four sums of the
+// step (model cost change, |x|^2, |d|^2, candidate cost) leave each workgroup as partials; the
+// workgroup that finishes last (a ticket counter; the grid is a handful of workgroups, so the
+// device-scope fences cost nothing that matters) adds them in workgroup order and writes the
+// step's scalars -- with `mail` also straight into host memory, followed by the sequence number
+// `seq`: the host polls for it instead of paying a copy and a stream synchronisation per iteration.
+constexpr int kSmallTailThreads = 256;       // 128 landmarks per workgroup
+constexpr int kSmallTailMaxGroups = 64;
+constexpr int kSmallTailMaxPoints = kSmallTailMaxGroups * (kSmallTailThreads / 2);
 
-__device__ __forceinline__ real block_sum_tail(real v, real *scratch /* >= 16 reals */)
+__device__ __forceinline__ real block_sum_tail(real v, real *scratch /* >= 4 reals */)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -480,10 +487,11 @@ small_tail_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, cons
                   const real *__restrict__ lmrec, const real *__restrict__ dcam, const unsigned char *__restrict__ cam_used,
                   const unsigned char *__restrict__ pt_used, real *__restrict__ dpt, real *__restrict__ t2,
                   real *__restrict__ rpy2, real *__restrict__ pts2, int want_cost, const int *__restrict__ info,
-                  real *__restrict__ out, unsigned long long *mail, unsigned long long seq)
+                  real *partial, int *ticket, real *__restrict__ out, unsigned long long *mail, unsigned long long seq)
 {
     __shared__ CamData scams[kSmallSolveN / 6], scams2[kSmallSolveN / 6];
-    __shared__ real x2[kSmallSolveN], red[kSmallTailThreads / 64];
+    __shared__ real x2[kSmallSolveN], sc2[kSmallSolveN], red[kSmallTailThreads / 64];
+    __shared__ int s_last;
     const int tid = threadIdx.x;
     real xn = 0, dn = 0, mcc = 0, cost = 0;
     {
@@ -497,24 +505,28 @@ small_tail_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, cons
         const real x = k < 3 ? t[3 * c + k] : rpy[3 * c + k - 3];
         const real d = used ? dcam[tid] : real(0);
         x2[tid] = x + d;
-        if (k < 3) t2[3 * c + k] = x + d; else rpy2[3 * c + k - 3] = x + d;
-        if (used) { xn = x * x; dn = d * d; }
+        if (blockIdx.x == 0) {
+            if (k < 3) t2[3 * c + k] = x + d; else rpy2[3 * c + k - 3] = x + d;
+            if (used) { xn = x * x; dn = d * d; }
+        }
+    }
+    __syncthreads();
+    if (tid < 3 * Nc) {                                   // one angle per thread: the three sincos of a camera side by side
+        const int c = tid / 3, k = tid % 3;
+        sincos(x2[6 * c + 3 + k], &sc2[2 * tid], &sc2[2 * tid + 1]);
     }
     __syncthreads();
     if (tid < Nc) {
-        real sr, cr, sp, cp, sy, cy;
-        sincos(x2[6 * tid + 3], &sr, &cr);
-        sincos(x2[6 * tid + 4], &sp, &cp);
-        sincos(x2[6 * tid + 5], &sy, &cy);
         // cam_from_sincos reads the translation as t[3 c + k]
         const real tt[3] = { x2[6 * tid], x2[6 * tid + 1], x2[6 * tid + 2] };
-        scams2[tid] = cam_from_sincos(tt, 0, sr, cr, sp, cp, sy, cy);
+        const real *q = sc2 + 6 * tid;
+        scams2[tid] = cam_from_sincos(tt, 0, q[0], q[1], q[2], q[3], q[4], q[5]);
     }
     __syncthreads();
     // two lanes per landmark: each takes every other observation in both passes, the sums of the
     // back-substitution are united with one exchange between the neighbours
     const int sub = tid & 1;
-    for (int j = tid >> 1; j < Np; j += kSmallTailThreads / 2) {
+    for (int j = blockIdx.x * (kSmallTailThreads / 2) + (tid >> 1); j < Np; j += gridDim.x * (kSmallTailThreads / 2)) {
         const int b = pt_ptr[j], e = pt_ptr[j + 1];
         const real P[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
         real acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // q[3] | V[6] | sum u.r | sum u.u
@@ -594,18 +606,29 @@ small_tail_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, cons
     dn = block_sum_tail(dn, red);
     cost = block_sum_tail(cost, red);
     if (tid == 0) {
-        out[0] = mcc; out[1] = xn; out[2] = dn;
-        if (want_cost) out[3] = cost;
-        out[6] = (real)*info;
-        if (mail) {
-            // the eight scalars of the step straight into the host's (coherent, page-locked) mailbox,
-            // then the sequence number the host is polling for
-            real *m = reinterpret_cast<real *>(mail);
-            m[0] = mcc; m[1] = xn; m[2] = dn; m[3] = want_cost ? cost : out[3];
-            m[4] = out[4]; m[5] = out[5]; m[6] = (real)*info; m[7] = out[7];
-            __threadfence_system();
-            __hip_atomic_store(mail + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        real *p = partial + 4 * blockIdx.x;
+        p[0] = mcc; p[1] = xn; p[2] = dn; p[3] = cost;
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || tid != 0) return;
+    __threadfence();
+    *ticket = 0;                                        // ready for the next launch
+    mcc = xn = dn = cost = real(0);
+    for (int g = 0; g < (int)gridDim.x; g++) {
+        const volatile real *p = partial + 4 * g;
+        mcc += p[0]; xn += p[1]; dn += p[2]; cost += p[3];
+    }
+    out[0] = mcc; out[1] = xn; out[2] = dn;
+    if (want_cost) out[3] = cost;
+    out[6] = (real)*info;
+    if (mail) {
+        real *m = reinterpret_cast<real *>(mail);
+        m[0] = mcc; m[1] = xn; m[2] = dn; m[3] = want_cost ? cost : out[3];
+        m[4] = out[4]; m[5] = out[5]; m[6] = (real)*info; m[7] = out[7];
+        __threadfence_system();
+        __hip_atomic_store(mail + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

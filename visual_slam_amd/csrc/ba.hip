@@ -125,6 +125,8 @@ struct vs_ba {
     // in flight (r = 0 cameras, 1 points, 2 the arena staging).
     PinnedBuf<SmallOut, true> small_host;    // motion_only_solve_kernel's summary, written by the kernel, polled by the host
     int small_seq = 0;
+    PinnedBuf<real, true> cams_host;         // [t | rpy] as the motion-only kernel left them (valid while cams_host_valid)
+    bool cams_host_valid = false;
     bool init_has_gmax = false;              // the first pass of the solve left max |gradient| in scalars[4]
     PinnedBuf<real> param_stage;
     bool busy[3] = { false, false, false };
@@ -1406,6 +1408,14 @@ static bool stageable(const vs_ba *h, const void *src)
     (void)hipGetLastError();      // plain host memory is unknown to the runtime
     return true;
 }
+// memory a plain memcpy may write: unknown to the runtime, or page-locked host memory
+static bool host_pointer(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) return attr.type == hipMemoryTypeUnregistered || attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return true;
+}
 static int claim_stage(vs_ba *h, int region)
 {
     if (!h->param_stage.p) VS_TRY(h->param_stage.alloc(6 * (size_t)h->Nc + 3 * (size_t)h->Np));
@@ -1433,6 +1443,7 @@ int vs_ba_set_cameras(vs_ba_handle h, const double *t, const double *rpy)
         VS_HIP(hipStreamSynchronize(h->stream));
     }
     h->have_cams = true; h->linearized = false; h->have_scale = false; h->prelin = false;
+    h->cams_host_valid = false;
     return VS_OK;
 }
 
@@ -1745,11 +1756,16 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
             h->small_seq = 0;
         }
         const int seq = ++h->small_seq;
+        const bool poll = getenv("VS_BA_NO_MAILBOX") == nullptr;
+        if (poll && !h->cams_host.p) VS_TRY(h->cams_host.alloc(6 * (size_t)kSmallMaxCams));
         hipLaunchKernelGGL(motion_only_solve_kernel, dim3(1), dim3(kSmallThreads), 0, s, h->Nc, h->K, h->t.p, h->rpy.p,
-                           h->pts.p, h->cam_ptr.p, h->cpt.p, h->cuv.p, h->cam_used.p, h->hub, o, h->scale_c.p, h->small_host.p, seq);
+                           h->pts.p, h->cam_ptr.p, h->cpt.p, h->cuv.p, h->cam_used.p, h->hub, o, h->scale_c.p, h->small_host.p,
+                           poll ? h->cams_host.p : (real *)nullptr, seq);
         VS_TRY(launch_check("motion_only_solve_kernel"));
-        if (getenv("VS_BA_NO_MAILBOX") == nullptr) VS_TRY(wait_for_word(h, &h->small_host.p->seq, seq));
-        else {
+        if (poll) {
+            VS_TRY(wait_for_word(h, &h->small_host.p->seq, seq));
+            h->cams_host_valid = true;
+        } else {
             VS_HIP(hipStreamSynchronize(s));
             h->busy[0] = h->busy[1] = h->busy[2] = false;
         }
@@ -1762,6 +1778,7 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
         }
         return VS_OK;
     }
+    h->cams_host_valid = false;
     double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
     int it = 0, term = 1, nsucc = 0, invalid = 0;
     double cost = 0.0, cost0 = 0.0;
@@ -1863,6 +1880,13 @@ int vs_ba_get_cameras(vs_ba_handle h, double *t, double *rpy)
 {
     VS_CHECK(h != nullptr, VS_ERR_INVALID, "null handle");
     VS_CHECK(h->have_cams, VS_ERR_STATE, "cameras not set");
+    if (h->cams_host_valid) {        // the last solve left them in host memory
+        if ((!t || host_pointer(t)) && (!rpy || host_pointer(rpy))) {
+            if (t) memcpy(t, h->cams_host.p, 3 * (size_t)h->Nc * sizeof(real));
+            if (rpy) memcpy(rpy, h->cams_host.p + 3 * (size_t)h->Nc, 3 * (size_t)h->Nc * sizeof(real));
+            return VS_OK;
+        }
+    }
     if (t) VS_HIP(hipMemcpyAsync(t, h->t.p, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
     if (rpy) VS_HIP(hipMemcpyAsync(rpy, h->rpy.p, 3 * (size_t)h->Nc * sizeof(real), hipMemcpyDefault, h->stream));
     VS_HIP(hipStreamSynchronize(h->stream));

@@ -52,7 +52,7 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
                          const real *__restrict__ pts, const int *__restrict__ cam_ptr,
                          const int *__restrict__ cpt, const real *__restrict__ cuv,
                          const unsigned char *__restrict__ cam_used, HuberObs hub, vs_lm_options opt,
-                         real *__restrict__ scale_out, SmallOut *out, int seq)
+                         real *__restrict__ scale_out, SmallOut *out, real *cams_host, int seq)
 {
     __shared__ CamData cams[kSmallMaxCams], cams2[kSmallMaxCams];
     __shared__ real x[6 * kSmallMaxCams], x2[6 * kSmallMaxCams], scale[6 * kSmallMaxCams], dc[6 * kSmallMaxCams];
@@ -317,12 +317,15 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
     for (int i = tid; i < 6 * Nc; i += kSmallThreads) {
         const int c = i / 6, k = i % 6;
         if (k < 3) t_io[3 * c + k] = x[i]; else rpy_io[3 * c + k - 3] = x[i];
+        // ... and straight into host memory ([t | rpy]): reading the cameras back costs no GPU call
+        if (cams_host) cams_host[k < 3 ? 3 * c + k : 3 * Nc + 3 * c + k - 3] = x[i];
     }
     if (tid == 0) {
         out->initial_cost = cost0; out->final_cost = cost; out->final_radius = radius;
         out->iterations = it; out->successful_steps = nsucc; out->termination = term;
     }
     // the cameras above must be in memory before the host sees the sequence number
+    __threadfence_system();
     __syncthreads();
     if (tid == 0) {
         __threadfence_system();

@@ -120,6 +120,7 @@ void Optimizer::addReprojectionEdges(Problem &problem, Matrix3f K, std::list<std
     if (rc == VS_OK) rc = vs_ba_set_huber_first(problem.handle, 100.0);                   // :69,128
     if (rc == VS_OK) rc = vs_ba_set_observations(problem.handle, cam.data(), pt.data(), uv.data());
     problem.status = rc;
+    problem.points_constant = fix_camera_or_point;
     if (rc != VS_OK) problem.error = vs_last_error_string();
 }
 
@@ -131,15 +132,18 @@ bool Optimizer::solve()
     vs_lm_options o;
     vs_lm_default_options(&o);
     int rc = vs_ba_solve(problem_->handle, &o, &summary_);
-    std::vector<double> t(3 * poses_.size()), rpy(3 * poses_.size()), xyz(3 * points_.size());
+    // constant points (tracking.cc:99, solveCamera) are not read back: the solve cannot have moved them
+    const bool read_points = !problem_->points_constant;
+    std::vector<double> t(3 * poses_.size()), rpy(3 * poses_.size()), xyz(read_points ? 3 * points_.size() : 0);
     if (rc == VS_OK) rc = vs_ba_get_cameras(problem_->handle, t.data(), rpy.data());
-    if (rc == VS_OK) rc = vs_ba_get_points(problem_->handle, xyz.data());
+    if (rc == VS_OK && read_points) rc = vs_ba_get_points(problem_->handle, xyz.data());
     problem_->status = rc;
     if (rc != VS_OK) { problem_->error = vs_last_error_string(); return false; }
     for (size_t c = 0; c < poses_.size(); c++)
         for (int k = 0; k < 3; k++) { poses_[c].translation[k] = t[3 * c + k]; poses_[c].rotation[k] = rpy[3 * c + k]; }
-    for (size_t j = 0; j < points_.size(); j++)
-        for (int k = 0; k < 3; k++) points_[j][k] = xyz[3 * j + k];
+    if (read_points)
+        for (size_t j = 0; j < points_.size(); j++)
+            for (int k = 0; k < 3; k++) points_[j][k] = xyz[3 * j + k];
     return true;
 }
 

@@ -32,6 +32,7 @@ public:
     Problem &operator=(const Problem &) = delete;
     vs_ba_handle handle = nullptr;
     int status = VS_OK;                  // last vs_status; message in error
+    bool points_constant = false;        // the edges were added with every point constant: a solve leaves points_ as they are
     std::string error;
 };
 

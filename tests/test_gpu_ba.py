@@ -465,3 +465,28 @@ def test_small_window_solve_reports_an_indefinite_system(monkeypatch):
             monkeypatch.delenv("VS_BA_NO_SMALL_SOLVER")
     for how in ("fast", "slow"):
         assert out[how]["termination"] == 2 and out[how]["iterations"] == 5 and out[how]["successful_steps"] == 0
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 8])
+def test_small_window_speculative_linearisation_changes_nothing(monkeypatch, seed):
+    """The LM loop of a small window enqueues the linearisation at the candidate before the host has
+    the step's numbers (the radius comes from the device's own decision); a rejected step discards
+    it.  With and without: the same iterations, decisions, radius and parameters."""
+    sc = synth.make_ba_config("c1", seed=seed)
+    out, cams, pts = {}, {}, {}
+    for how in ("spec", "plain"):
+        if how == "plain":
+            monkeypatch.setenv("VS_BA_NO_SPECULATION", "1")
+        p = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv, huber_a=100.0)
+        out[how] = p.solve()
+        cams[how] = p.cameras(); pts[how] = p.points()
+        p.close()
+        if how == "plain":
+            monkeypatch.delenv("VS_BA_NO_SPECULATION")
+    a, b = out["spec"], out["plain"]
+    for key in ("termination", "iterations", "successful_steps"):
+        assert a[key] == b[key], key
+    assert a["successful_steps"] < a["iterations"] or seed != 0      # seed 0 holds a rejected step
+    assert abs(a["final_cost"] - b["final_cost"]) <= 1e-12 * b["final_cost"]
+    assert abs(a["radius"] - b["radius"]) <= 1e-12 * b["radius"]
+    assert rel(cams["spec"][0], cams["plain"][0]) < 1e-10 and rel(pts["spec"], pts["plain"]) < 1e-10

@@ -158,6 +158,7 @@ struct vs_ba {
     unsigned long long mail_seq = 0;
     DevBuf<real> tail_partial;               // small_tail_kernel: four sums per workgroup
     DevBuf<int> tail_ticket;                 // ... and its ticket counter (zero between launches)
+    DevBuf<real> radius_next;                // radius the tail kernel derived for the speculative linearisation
 
     real *S_diag() { return red.p; }
     real *S_off() { return red.p + (int64_t)Nc * 36; }
@@ -1096,7 +1097,15 @@ int cross_gpu_max(vs_ba *h, real *val)
     return launch_check("max_of_kernel");
 }
 
-struct StepScalars { real mcc, xnorm2, snorm2, cost_new; };
+struct StepScalars {
+    real mcc, xnorm2, snorm2, cost_new;
+    // small windows with speculation: the device's own decision and the radius it gave the
+    // linearisation that is already enqueued at the candidate
+    bool speculated = false, accepted_dev = false;
+    real radius_next = 0;
+};
+// what the LM loop tells a step so that the step's last kernel can take the decision itself
+struct StepContext { bool speculate = false; double cost_cur = 0; const vs_lm_options *opt = nullptr; };
 
 // Waits until *word == want: the last kernel of the stream writes it into coherent page-locked
 // memory after its results.  A stream synchronisation costs more than the kernels of a small
@@ -1152,7 +1161,7 @@ int unscaled_pass(vs_ba *h)
 // parameters (t2,rpy2,pts2) on the device; fills sc (host).  *numeric_fail set when the reduced
 // system is not positive definite.
 int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScalars *sc,
-                   bool *numeric_fail, bool want_candidate_cost)
+                   bool *numeric_fail, bool want_candidate_cost, const StepContext *ctx = nullptr)
 {
     hipStream_t s = h->stream;
     const int Nc = h->Nc, Np = h->Np;
@@ -1247,16 +1256,35 @@ int lm_step_device(vs_ba *h, double radius, double min_d, double max_d, StepScal
             VS_TRY(h->tail_ticket.alloc(1));
             VS_HIP(hipMemsetAsync(h->tail_ticket.p, 0, sizeof(int), s));
         }
+        // Speculation: the step is usually accepted, and the next step then starts with a
+        // linearisation at the candidate.  Enqueued here, behind the tail kernel and before the host
+        // has seen the step's numbers, it runs while the host is still on its way back; its damping
+        // radius is the one the tail kernel derives on the device.  A step that is not accepted
+        // simply linearises again (as it does without speculation, the radius having changed).
+        const bool speculate = use_mail && ctx && ctx->speculate && want_candidate_cost;
+        TailDecision dec{};
+        if (speculate) {
+            if (!h->radius_next.p) VS_TRY(h->radius_next.alloc(1));
+            dec = TailDecision{ (real)ctx->cost_cur, (real)radius, (real)ctx->opt->min_relative_decrease,
+                                (real)ctx->opt->max_trust_region_radius, (real)ctx->opt->parameter_tolerance,
+                                (real)ctx->opt->function_tolerance, h->radius_next.p };
+        }
         hipLaunchKernelGGL(small_tail_kernel, dim3(groups), dim3(kSmallTailThreads), 0, s, Np, Nc, h->K, h->cams.p, h->t.p, h->rpy.p,
                            h->pts.p, h->pt_ptr.p, h->lcam.p, h->luv.p, h->hub, h->hub_w.p, h->lmrec.p, h->dcam.p,
                            h->cam_used.p, h->pt_used.p, h->dpt.p, h->t2.p, h->rpy2.p, h->pts2.p, (int)want_candidate_cost,
                            h->info.p, h->tail_partial.p, h->tail_ticket.p, h->scalars.p,
-                           use_mail ? h->mail.p : (unsigned long long *)nullptr, seq);
+                           use_mail ? h->mail.p : (unsigned long long *)nullptr, seq, dec);
         VS_TRY(launch_check("small_tail_kernel"));
+        if (speculate) {
+            PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)min_d, (real)max_d };
+            pd.radius_dev = h->radius_next.p;
+            VS_TRY(linearize(h, h->t2.p, h->rpy2.p, h->pts2.p, pd));
+        }
         if (use_mail) {
             VS_TRY(wait_for_word(h, h->mail.p + 8, seq));
             const real *m = reinterpret_cast<const real *>(h->mail.p);
             sc->mcc = m[0]; sc->xnorm2 = m[1]; sc->snorm2 = m[2]; sc->cost_new = m[3];
+            sc->speculated = speculate; sc->accepted_dev = m[7] != 0.0; sc->radius_next = m[5];
             *numeric_fail = m[6] != 0.0;
             if (h->step_has_gmax) h->host_scalars.p[8] = m[4];
             return VS_OK;
@@ -1804,6 +1832,7 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
             bool gmax_pending = false, gmax_enqueued = false;
             const bool small_window = !h->fix_points && h->nb_off > 0 && 6 * h->Nc <= kSmallSolveN && h->world == 1 &&
                                       h->Np <= kSmallPrepMaxPoints && getenv("VS_BA_NO_SMALL_SOLVER") == nullptr;
+            const bool speculation = getenv("VS_BA_NO_SPECULATION") == nullptr;
             while (true) {
                 if (it >= o.max_num_iterations || radius < o.min_trust_region_radius) {
                     term = it >= o.max_num_iterations ? 1 : 0;
@@ -1817,7 +1846,8 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
                 it++;
                 StepScalars sc{};
                 bool fail = false;
-                VS_TRY(lm_step_device(h, radius, o.min_lm_diagonal, o.max_lm_diagonal, &sc, &fail, true));
+                StepContext ctx{ small_window && speculation, cost, &o };
+                VS_TRY(lm_step_device(h, radius, o.min_lm_diagonal, o.max_lm_diagonal, &sc, &fail, true, &ctx));
                 if (gmax_pending) {
                     gmax_pending = false;
                     if (h->host_scalars.p[8] <= o.gradient_tolerance) { it--; term = 0; break; }
@@ -1837,15 +1867,21 @@ int vs_ba_solve(vs_ba_handle h, const vs_lm_options *opts, vs_lm_summary *summar
                     std::swap(h->t.p, h->t2.p); std::swap(h->rpy.p, h->rpy2.p);
                     if (!h->fix_points) std::swap(h->pts.p, h->pts2.p);
                     cost = sc.cost_new; nsucc++;
+                    decrease_factor = 2.0;
+                    if (sc.speculated && sc.accepted_dev) {
+                        // the linearisation at this point is already enqueued, with the radius the
+                        // device derived from the same numbers
+                        radius = sc.radius_next;
+                    } else {
                     double f = 1.0 - std::pow(2.0 * rho - 1.0, 3.0);
                     if (f < 1.0 / 3.0) f = 1.0 / 3.0;
                     radius = std::min(radius / f, o.max_trust_region_radius);
-                    decrease_factor = 2.0;
                     // gradient at the accepted point, from the pass the next step starts from (the
                     // gradient does not depend on the damping)
                     PointDamping pd{ nullptr, h->scale_p.p, (real)radius, (real)o.min_lm_diagonal, (real)o.max_lm_diagonal };
                     VS_TRY(linearize(h, h->t.p, h->rpy.p, h->pts.p, pd));
                     VS_TRY(exchange_reduced(h));
+                    }
                     h->prelin = true;
                     h->prelin_radius = radius;
                     // (a small window's next step computes the gradient test itself)

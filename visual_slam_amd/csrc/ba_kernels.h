@@ -223,6 +223,7 @@ struct PointDamping {
     const real *scale_p;
     real radius, min_d, max_d;
     const int *lam_map;     // lam_p is in the caller's landmark numbering: entry of landmark j at lam_map[j] (NULL: j)
+    const real *radius_dev; // when set, the radius is read from device memory (a step enqueued before the host knows it)
 };
 
 struct HuberObs {
@@ -355,6 +356,7 @@ __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int
                 l0 = dmp[0]; l1 = dmp[1]; l2 = dmp[2];
             } else if (damp.scale_p) {
                 const real d[3] = { V[0], V[3], V[5] };
+                const real lm_radius = damp.radius_dev ? *damp.radius_dev : damp.radius;
                 real l[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
@@ -362,7 +364,7 @@ __device__ __forceinline__ real landmark_lanes(int j, int sl, int Np, int b, int
                     real x = s2 * d[k];
                     x = x < damp.min_d ? damp.min_d : x;
                     x = x > damp.max_d ? damp.max_d : x;
-                    l[k] = x * fast_rcp(damp.radius * s2);
+                    l[k] = x * fast_rcp(lm_radius * s2);
                 }
                 l0 = l[0]; l1 = l[1]; l2 = l[2];
             }

@@ -469,6 +469,15 @@ constexpr int kSmallTailThreads = 256;       // 128 landmarks per workgroup
 constexpr int kSmallTailMaxGroups = 64;
 constexpr int kSmallTailMaxPoints = kSmallTailMaxGroups * (kSmallTailThreads / 2);
 
+// What the last workgroup needs to take the LM loop's accept / reject decision itself (the host takes
+// it again from the same numbers): the next radius goes to *radius_next, which the linearisation
+// enqueued behind this kernel -- at the candidate, before the host knows whether the step is
+// accepted -- reads as its damping radius.  radius_next == nullptr: no decision wanted.
+struct TailDecision {
+    real cost_cur, radius, min_relative_decrease, max_radius, parameter_tolerance, function_tolerance;
+    real *radius_next;
+};
+
 __device__ __forceinline__ real block_sum_tail(real v, real *scratch /* >= 4 reals */)
 {
 #pragma unroll
@@ -490,7 +499,8 @@ small_tail_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, cons
                   const real *__restrict__ lmrec, const real *__restrict__ dcam, const unsigned char *__restrict__ cam_used,
                   const unsigned char *__restrict__ pt_used, real *__restrict__ dpt, real *__restrict__ t2,
                   real *__restrict__ rpy2, real *__restrict__ pts2, int want_cost, const int *__restrict__ info,
-                  real *partial, int *ticket, real *__restrict__ out, unsigned long long *mail, unsigned long long seq)
+                  real *partial, int *ticket, real *__restrict__ out, unsigned long long *mail, unsigned long long seq,
+                  TailDecision dec)
 {
     __shared__ CamData scams[kSmallSolveN / 6], scams2[kSmallSolveN / 6];
     __shared__ real x2[kSmallSolveN], sc2[kSmallSolveN], red[kSmallTailThreads / 64];
@@ -626,10 +636,30 @@ small_tail_kernel(int Np, int Nc, Intr K, const CamData *__restrict__ cams, cons
     out[0] = mcc; out[1] = xn; out[2] = dn;
     if (want_cost) out[3] = cost;
     out[6] = (real)*info;
+    // the decision vs_ba_solve's loop takes from these numbers, in its order of tests
+    real accepted = real(0), radius_next = dec.radius;
+    if (dec.radius_next) {
+        if (*info == 0 && mcc > real(0)) {
+            const real xnorm = sqrt(xn), snorm = sqrt(dn);
+            const real change = dec.cost_cur - cost;
+            if (!(snorm <= dec.parameter_tolerance * (xnorm + dec.parameter_tolerance)) &&
+                !(fabs(change) <= dec.function_tolerance * dec.cost_cur)) {
+                const real rho = change / mcc;
+                if (rho > dec.min_relative_decrease) {
+                    accepted = real(1);
+                    const real y = real(2) * rho - real(1);
+                    real f = real(1) - y * y * y;
+                    if (f < real(1) / real(3)) f = real(1) / real(3);
+                    radius_next = fmin(dec.radius / f, dec.max_radius);
+                }
+            }
+        }
+        *dec.radius_next = radius_next;
+    }
     if (mail) {
         real *m = reinterpret_cast<real *>(mail);
         m[0] = mcc; m[1] = xn; m[2] = dn; m[3] = want_cost ? cost : out[3];
-        m[4] = out[4]; m[5] = out[5]; m[6] = (real)*info; m[7] = out[7];
+        m[4] = out[4]; m[5] = radius_next; m[6] = (real)*info; m[7] = accepted;
         __threadfence_system();
         __hip_atomic_store(mail + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

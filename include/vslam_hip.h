@@ -160,6 +160,9 @@ int vs_comm_create(vs_comm_handle *c, int32_t rank, int32_t world, const void *i
 int vs_comm_destroy(vs_comm_handle c);
 /* In-place sum of n doubles at a device pointer across the ranks, enqueued on hip_stream. */
 int vs_comm_allreduce_sum(vs_comm_handle c, double *device_buf, int64_t n, void *hip_stream);
+/* Every rank's n doubles at device_send end up at device_recv + rank * n on every rank (the
+ * collective vs_ba_exchange_reduced is built on), enqueued on hip_stream. */
+int vs_comm_allgather(vs_comm_handle c, const double *device_send, double *device_recv, int64_t n, void *hip_stream);
 /* Combines the shards' partial reduce buffers (no counterpart in the reference, which is one
  * process): after it every rank's vs_ba_reduce_buffer() holds the sum over the ranks.  The
  * landmarks of a shard see one contiguous range of cameras, so a rank sends only the rows of that

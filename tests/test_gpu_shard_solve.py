@@ -139,6 +139,11 @@ def test_native_communicator_with_one_rank():
     _lib.check(lib.vs_comm_allreduce_sum(comm, C.c_void_p(x.data_ptr()), C.c_int64(1000), None))
     torch.cuda.synchronize()
     assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64))
+    # the all-gather the segment exchange is built on (one rank: the receive buffer is the send buffer)
+    y = torch.zeros(1000, dtype=torch.float64, device="cuda")
+    _lib.check(lib.vs_comm_allgather(comm, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_int64(1000), None))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), torch.arange(1000, dtype=torch.float64))
     _lib.check(lib.vs_ba_set_comm(b.h, None))
     b.close()
     _lib.check(lib.vs_comm_destroy(comm))

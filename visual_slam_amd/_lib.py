@@ -29,7 +29,7 @@ SYMBOLS = [
     "vs_triangulate_tracks",
     "vs_match_two_way_noalloc",
     "vs_comm_unique_id", "vs_comm_create", "vs_comm_destroy", "vs_comm_allreduce_sum", "vs_ba_set_comm",
-    "vs_ba_set_allgather", "vs_ba_exchange_reduced", "vs_ba_exchange_size",
+    "vs_ba_set_allgather", "vs_ba_exchange_reduced", "vs_ba_exchange_size", "vs_comm_allgather",
 ]
 
 

@@ -146,4 +146,10 @@ int vs_comm_allreduce_sum(vs_comm_handle c, double *device_buf, int64_t n, void 
     return comm_allreduce(c, device_buf, n, false, (hipStream_t)hip_stream);
 }
 
+int vs_comm_allgather(vs_comm_handle c, const double *device_send, double *device_recv, int64_t n, void *hip_stream)
+{
+    VS_CHECK(c != nullptr && (n == 0 || (device_send && device_recv)), VS_ERR_INVALID, "null argument");
+    return comm_allgather(c, device_send, device_recv, n, (hipStream_t)hip_stream);
+}
+
 }  // extern "C"

@@ -93,10 +93,19 @@ bcr_trsm_kernel(int level, int Nb, int w, const real *__restrict__ D, const real
     }
     __syncthreads();
     // right-looking sweep: solve panel q with its block inverse, then take its contribution out of
-    // every row below
+    // every row below.  The inverse of the next panel's diagonal block is fetched while this
+    // panel's update runs.
+    real lt_next[kBcrT * kBcrT / 256];
+#pragma unroll
+    for (int u = 0; u < kBcrT * kBcrT / 256; u++) lt_next[u] = Li[tid + u * 256];
     for (int q = 0; q < nt; q++) {
-        for (int e = tid; e < kBcrT * kBcrT; e += 256) Lt[e / kBcrT][e % kBcrT] = Li[(int64_t)q * kBcrT * kBcrT + e];
+#pragma unroll
+        for (int u = 0; u < kBcrT * kBcrT / 256; u++) { const int e = tid + u * 256; Lt[e / kBcrT][e % kBcrT] = lt_next[u]; }
         __syncthreads();
+        if (q + 1 < nt) {
+#pragma unroll
+            for (int u = 0; u < kBcrT * kBcrT / 256; u++) lt_next[u] = Li[(int64_t)(q + 1) * kBcrT * kBcrT + tid + u * 256];
+        }
         real out[4] = { 0, 0, 0, 0 };
 #pragma unroll 8
         for (int k = 0; k < kBcrT; k++) {
@@ -151,24 +160,44 @@ bcr_trsm_kernel(int level, int Nb, int w, const real *__restrict__ D, const real
 
 constexpr int kBcrKC = 16;          // rows of P and Q staged per step of a tile product
 
-// 32 x 32 tile of  P^T Q  (P, Q: w x w row-major, the sum runs over their rows) by ONE wave: 16
-// rows of both operands at a time pass through the wave's own LDS area, every lane adds a 4 x 4
-// patch (rows r4*4.., columns c4*4.. of the tile): four 16-byte LDS reads per 16 FMAs.  Only this
-// wave touches Ps / Qs, and a wave's LDS operations execute in order: no workgroup barrier.
-__device__ __forceinline__ void bcr_tile_ptq(const real *__restrict__ P, const real *__restrict__ Q, int w,
+// 32 x 32 tile of  P0^T Q0 (+ P1^T Q1)  (P, Q: w x w row-major, the sums run over their rows) by ONE
+// wave: 16 rows of both operands at a time pass through the wave's own LDS area, every lane adds a
+// 4 x 4 patch (rows r4*4.., columns c4*4.. of the tile): four 16-byte LDS reads per 16 FMAs.  The
+// next 16 rows are fetched into registers while the current ones are multiplied (the products of a
+// slab take less time than its trip to L2, and a level of the reduction is a few such tiles per
+// wave: without the prefetch the kernel is a chain of exposed memory latencies).  Only this wave
+// touches Ps / Qs, and a wave's LDS operations execute in order: no workgroup barrier.
+__device__ __forceinline__ void bcr_tile_ptq(const real *__restrict__ P0, const real *__restrict__ Q0,
+                                             const real *__restrict__ P1, const real *__restrict__ Q1, int w,
                                              int i0, int j0, real (*Ps)[kBcrT], real (*Qs)[kBcrT],
                                              int lane, real (*acc)[4])
 {
     const int r4 = lane >> 3, c4 = lane & 7;
-    for (int k0 = 0; k0 < w; k0 += kBcrKC) {
+    constexpr int kPer = kBcrKC * kBcrT / kWave;            // elements of P (and of Q) a lane moves per slab
+    const int slabs_one = w / kBcrKC, n_slabs = P1 ? 2 * slabs_one : slabs_one;
+    real pn[kPer], qn[kPer];
+    auto fetch = [&](int slab) {
+        const bool second = slab >= slabs_one;
+        const real *P = second ? P1 : P0, *Q = second ? Q1 : Q0;
+        const int k0 = (second ? slab - slabs_one : slab) * kBcrKC;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int e = lane + q * kWave, k = e / kBcrT, m = e % kBcrT;
+            pn[q] = P[(int64_t)(k0 + k) * w + i0 + m];
+            qn[q] = Q[(int64_t)(k0 + k) * w + j0 + m];
+        }
+    };
+    fetch(0);
+    for (int slab = 0; slab < n_slabs; slab++) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int e = lane; e < kBcrKC * kBcrT; e += kWave) {
-            const int k = e / kBcrT, m = e % kBcrT;
-            Ps[k][m] = P[(int64_t)(k0 + k) * w + i0 + m];
-            Qs[k][m] = Q[(int64_t)(k0 + k) * w + j0 + m];
+        for (int q = 0; q < kPer; q++) {
+            const int e = lane + q * kWave, k = e / kBcrT, m = e % kBcrT;
+            Ps[k][m] = pn[q];
+            Qs[k][m] = qn[q];
         }
         __builtin_amdgcn_wave_barrier();
+        if (slab + 1 < n_slabs) fetch(slab + 1);
 #pragma unroll 4
         for (int k = 0; k < kBcrKC; k++) {
             const double2 p01 = *reinterpret_cast<const double2 *>(&Ps[k][r4 * 4]);
@@ -243,8 +272,8 @@ bcr_update_kernel(int level, int Nb, int w, int n_rem, const real *__restrict__ 
         int ti = 0, rem = tile;
         while (rem > ti) { rem -= ti + 1; ti++; }   // tile -> (ti, tj), tj <= ti
         const int tj = rem;
-        bcr_tile_ptq(Gr + cL * ww, Gr + cL * ww, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
-        if (cR < Nb) bcr_tile_ptq(Gl + cR * ww, Gl + cR * ww, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
+        const real *G1 = cR < Nb ? Gl + cR * ww : nullptr;
+        bcr_tile_ptq(Gr + cL * ww, Gr + cL * ww, G1, G1, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
         real *out = D + t * ww + (int64_t)(ti * kBcrT + r4 * 4) * w + tj * kBcrT + c4 * 4;
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -255,7 +284,7 @@ bcr_update_kernel(int level, int Nb, int w, int n_rem, const real *__restrict__ 
         const int l = c - s, r = c + s;
         if (l < 0 || r >= Nb || c >= Nb || tile >= nt * nt) return;
         const int ti = tile / nt, tj = tile % nt;   // rows of r, columns of l
-        bcr_tile_ptq(Gr + c * ww, Gl + c * ww, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
+        bcr_tile_ptq(Gr + c * ww, Gl + c * ww, nullptr, nullptr, w, ti * kBcrT, tj * kBcrT, Ps[wv], Qs[wv], lane, acc);
         real *out = C + l * ww + (int64_t)(ti * kBcrT + r4 * 4) * w + tj * kBcrT + c4 * 4;
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -311,30 +340,58 @@ bcr_backsub_kernel(int level, int Nb, int w, const real *__restrict__ D, const r
     }
     __syncthreads();
     const real *Lc = D + c * ww;
-    for (int p = nt - 1; p >= 0; p--) {
-        // u_i = v[32p+i] - sum_{rows below the panel} L[row][32p+i] x[row];  then x_p = Linv_p^T u
-        if (tid < kBcrT * 8) {
-            const int i = tid & 31, part = tid >> 5;        // 8 partial sums per column
-            real sum = real(0);
-            for (int row = (p + 1) * kBcrT + part; row < w; row += 8) sum = fma(Lc[(int64_t)row * w + p * kBcrT + i], xs[row], sum);
-            part_s[part][i] = sum;
+    // Panels from the last to the first:  u_i = v[32p+i] - sum_{rows below the panel} L[row][32p+i] x[row],
+    // then x_p = Linv_p^T u.  Thread (i, part) of 32 x 8 adds every eighth row / four of the 32
+    // terms; the factor entries and block-inverse entries a panel needs do not depend on the
+    // solution, so those of panel p - 1 are fetched while panel p is being solved (a panel is
+    // otherwise two exposed trips to L2 and a chain of 32 dependent fmas).
+    constexpr int kMaxT = (kBcrMaxW - kBcrT) / 8;
+    const int i = tid & 31, part = tid >> 5;
+    real lrow[kMaxT], lrow_next[kMaxT], li[4], li_next[4];
+    auto fetch_panel = [&](int p, real *lr, real *lq) {
+#pragma unroll
+        for (int t = 0; t < kMaxT; t++) {
+            const int row = (p + 1) * kBcrT + part + 8 * t;
+            lr[t] = row < w ? Lc[(int64_t)row * w + p * kBcrT + i] : real(0);
         }
+        const real *Li = Linv + ((int64_t)c * nt + p) * kBcrT * kBcrT;
+#pragma unroll
+        for (int m = 0; m < 4; m++) lq[m] = Li[(part * 4 + m) * kBcrT + i];     // (L^-1)^T: column i of the inverse
+    };
+    fetch_panel(nt - 1, lrow, li);
+    for (int p = nt - 1; p >= 0; p--) {
+        if (p > 0) fetch_panel(p - 1, lrow_next, li_next);
+        real sum = real(0);
+#pragma unroll
+        for (int t = 0; t < kMaxT; t++) {
+            const int row = (p + 1) * kBcrT + part + 8 * t;
+            if (row < w) sum = fma(lrow[t], xs[row], sum);
+        }
+        part_s[part][i] = sum;
         __syncthreads();
         if (tid < kBcrT) {
             real u = v[p * kBcrT + tid];
 #pragma unroll
-            for (int part = 0; part < 8; part++) u -= part_s[part][tid];
+            for (int q = 0; q < 8; q++) u -= part_s[q][tid];
             u_s[tid] = u;
         }
         __syncthreads();
+        real ps = real(0);
+#pragma unroll
+        for (int m = 0; m < 4; m++) ps = fma(li[m], u_s[part * 4 + m], ps);
+        part_s[part][i] = ps;
+        __syncthreads();
         if (tid < kBcrT) {
-            const real *Li = Linv + ((int64_t)c * nt + p) * kBcrT * kBcrT;
-            real sum = real(0);
-#pragma unroll 8
-            for (int m = 0; m < kBcrT; m++) sum = fma(Li[m * kBcrT + tid], u_s[m], sum);   // (L^-1)^T
-            xs[p * kBcrT + tid] = sum;
+            real tot = part_s[0][tid];
+#pragma unroll
+            for (int q = 1; q < 8; q++) tot += part_s[q][tid];
+            xs[p * kBcrT + tid] = tot;
         }
         __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kMaxT; t++) lrow[t] = lrow_next[t];
+#pragma unroll
+        for (int m = 0; m < 4; m++) li[m] = li_next[m];
     }
     for (int i = tid; i < w; i += 256) x[(int64_t)c * w + i] = xs[i];
 }

@@ -1357,14 +1357,6 @@ int gradient_max_enqueue(vs_ba *h)
     return VS_OK;
 }
 
-int gradient_max(vs_ba *h, real *out)
-{
-    VS_TRY(gradient_max_enqueue(h));
-    VS_HIP(hipStreamSynchronize(h->stream));
-    *out = h->host_scalars.p[8];
-    return VS_OK;
-}
-
 }  // namespace
 
 extern "C" {

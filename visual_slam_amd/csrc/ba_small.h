@@ -1,5 +1,9 @@
-// Motion-only bundle adjustment of a small window in ONE launch (included by ba.hip only).
+// Kernels for small windows (included by ba.hip only): the motion-only LM loop in ONE launch, and the
+// fused set-up (small_scales_kernel, small_prepare_kernel) and tail (small_tail_kernel) of a full-BA LM
+// step, which leave the general landmark / block / factorisation kernels six launches per iteration
+// instead of fourteen.
 //
+// Motion-only bundle adjustment of a small window in one launch:
 // The reference's live mode is Tracking::solveCamera (src/core/tracking.cc:79-120): every point is
 // constant (fix_camera_or_point = true, src/core/optimizer.cc:134-137), a handful of keyframes, a
 // few thousand observations, ceres::Solve with its default Levenberg-Marquardt loop -- twice per

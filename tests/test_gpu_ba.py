@@ -414,7 +414,7 @@ def test_one_launch_motion_only_solver_equals_the_general_path(orc, monkeypatch,
     assert rel(df, ds) < 1e-7 and abs(mf - ms) < 1e-7 * abs(ms)
 
 
-@pytest.mark.parametrize("shape", [(10, 500, 6, 31), (16, 400, 5, 32), (3, 60, 3, 33), (12, 300, 4, 34)])
+@pytest.mark.parametrize("shape", [(10, 500, 6, 31), (16, 400, 5, 32), (3, 60, 3, 33), (12, 300, 4, 34), (24, 900, 5, 35), (32, 700, 4, 36)])
 def test_small_window_reduced_solve_equals_the_general_solver(orc, monkeypatch, shape):
     """Full BA of a small window (the reference's Tracking::solvePoints, src/core/tracking.cc:122-163)
     takes its LM step through one fused launch (damping, assembly, L D L^T, solve, gradient test);

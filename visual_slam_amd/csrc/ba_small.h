@@ -351,7 +351,7 @@ motion_only_solve_kernel(int Nc, Intr K, real *__restrict__ t_io, real *__restri
 // (A factorisation inside this kernel was built and measured: one workgroup, L D L^T with the
 // elements in registers, one barrier per column -- 1.05 us per column, 65 us at 60 unknowns,
 // against 27 us for the panel kernels of dense_solve.h; see tools/micro/small_solve_time.hip.)
-constexpr int kSmallSolveN = 90;            // 15 cameras: below the size at which the general path may choose band storage
+constexpr int kSmallSolveN = 192;           // 32 cameras; the system is always factored on dense storage (one workgroup, dense_solve.h)
 constexpr int kSmallPrepMaxPoints = 16384;  // landmark gradients scanned by one workgroup
 constexpr int kSmallSolveThreads = 1024;    // the kernel is a few dependent memory round trips: more threads, fewer turns per loop
 

@@ -490,3 +490,28 @@ def test_small_window_speculative_linearisation_changes_nothing(monkeypatch, see
     assert abs(a["final_cost"] - b["final_cost"]) <= 1e-12 * b["final_cost"]
     assert abs(a["radius"] - b["radius"]) <= 1e-12 * b["radius"]
     assert rel(cams["spec"][0], cams["plain"][0]) < 1e-10 and rel(pts["spec"], pts["plain"]) < 1e-10
+
+
+@pytest.mark.parametrize("max_it", [1, 2, 4])
+def test_small_window_solve_cut_short_by_the_iteration_limit(orc, monkeypatch, max_it):
+    """The loop ends on max_num_iterations right after an accepted step: the gradient test of that
+    point has not been seen yet (it rides on the next step, which never comes) and is taken
+    separately; the speculative linearisation at the accepted point is what it reads.  Same
+    summary and parameters as the general path and the oracle."""
+    sc = synth.make_ba_config("c1", seed=2)
+    ref, fast = both(orc, sc)
+    slow = BAProblem.from_arrays(sc.K, sc.t0, sc.rpy0, sc.pts0, sc.cam, sc.pt, sc.uv)
+    out_f = fast.solve(max_num_iterations=max_it)
+    monkeypatch.setenv("VS_BA_NO_SMALL_SOLVER", "1")
+    out_s = slow.solve(max_num_iterations=max_it)
+    monkeypatch.delenv("VS_BA_NO_SMALL_SOLVER")
+    opts = orc.DEFAULT_OPTS.copy(); opts[0] = max_it
+    out_r = ref.solve(opts)
+    for key in ("termination", "iterations", "successful_steps"):
+        assert out_f[key] == out_s[key] == out_r[key], key
+    assert abs(out_f["final_cost"] - out_s["final_cost"]) < 1e-10 * out_s["final_cost"]
+    assert abs(out_f["final_cost"] - out_r["final_cost"]) < 1e-9 * out_r["final_cost"]
+    assert rel(fast.cameras()[0], slow.cameras()[0]) < 1e-9 and rel(fast.points(), slow.points()) < 1e-9
+    # the handle is usable afterwards: a further solve continues from where the first stopped
+    a, b = fast.solve(max_num_iterations=3), slow.solve(max_num_iterations=3)   # slow now also takes the small path
+    assert a["iterations"] == b["iterations"] and abs(a["final_cost"] - b["final_cost"]) < 1e-9 * b["final_cost"]

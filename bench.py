@@ -195,7 +195,9 @@ def bench_ba(args, rank, world, dist, torch, comm):
                                       "and finalize when a block spans several work items. HIP-event intervals, "
                                       "each carrying ~5 us of event overhead, so the sum is longer than the timed step",
                                dominant_kernel=dom, kernels_ms=k_ms, pipeline_ms=float(ms[5]),
-                               algorithmic_bytes=int(alg))
+                               algorithmic_bytes=int(alg),
+                               # the same bytes over the dominant kernel's own HIP-event duration
+                               frac_dominant_kernel=(alg / (k_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms.get(dom) else None)
     if rank == 0 and world == 1 and not args.no_extra:
         # throughput with two independent problems in flight (a second handle on a second stream,
         # steps alternating): one problem's landmark kernel runs beside the other's block kernel.

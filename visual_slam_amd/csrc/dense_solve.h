@@ -7,6 +7,8 @@
 // every kernel below touches in-band elements only.  The caller chooses ld as a multiple of 16
 // elements so that the 16-element row segments of the update tiles are aligned 128-byte lines.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <hip/hip_runtime.h>
 #include "ba_kernels.h"
@@ -429,7 +431,11 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
     A += (int64_t)blockIdx.x * batch_stride_A;
     Linv += (int64_t)blockIdx.x * batch_stride_Linv;
     __shared__ real Wn[kNB][kNB + 1];                            // diagonal block of the next panel
-    __shared__ real Ld[kNB][kNB + 1];                            // Ld[c][i] = L[i][c] of the current block
+    // Ld[c][i] = L[i][c] of the current block.  It lives in Wn's storage: the factoring wave has the
+    // whole block in registers before it writes the factor, and the factor has gone to global
+    // memory (one more barrier) before the next block is assembled there.  The 8 KB this saves
+    // are what lets a dense system of 50 cameras keep both panel images in LDS.
+    real (*Ld)[kNB + 1] = Wn;
     __shared__ __attribute__((aligned(16))) real wimg[48 * kSS];  // scratch of the factoring wave
     __shared__ __attribute__((aligned(16))) real Li[kNB][kXS];    // inverse of the block's factor
     __shared__ int bad_s;
@@ -483,14 +489,16 @@ chol_window_kernel(real *__restrict__ A, int n, int64_t ld, int bw, int *__restr
 #ifdef VS_CHOL_TIMING
         unsigned long long st2 = __builtin_readcyclecounter();
 #endif
-        // the block's factor and its inverse go to global memory; Wn is reset to the identity
+        // the block's factor and its inverse go to global memory; then Wn (which held the factor)
+        // is reset to the identity
         for (int e = tid; e < kNB * kNB; e += kCholThreads) {
             const int r = e / kNB, c = e % kNB;
             if (r >= c && r < nb) A[(int64_t)(k0 + r) * ld + k0 + c] = Ld[c][r];
             Lp[e] = Li[r][c];
-            Wn[r][c] = r == c ? real(1) : real(0);
         }
         if (rem <= 0) break;                                      // uniform: last panel
+        __syncthreads();
+        for (int e = tid; e < kNB * kNB; e += kCholThreads) Wn[e / kNB][e % kNB] = e / kNB == e % kNB ? real(1) : real(0);
         // Band storage: the rows that enter the window two panels from now are first touched here,
         // one cache line per thread, so that their first real use does not wait for HBM.  The value
         // is only consumed (by an empty asm) at the end of the panel.
@@ -1011,6 +1019,10 @@ __global__ void solve6_kernel(int Nc, const real *__restrict__ S_diag, const rea
 
 // Dynamic LDS beyond the default limit for the single-workgroup Cholesky kernels: a per-device
 // function attribute, set once per GPU.
+constexpr int kLdsPerWorkgroup = 160 * 1024;     // gfx950
+// dynamic LDS the look-ahead kernel may take beside its static arrays (0 until the limit is raised)
+static int g_window_max_dyn[64] = {};
+
 static inline int chol_window_raise_lds_limit()
 {
     static std::mutex lds_mutex;
@@ -1020,8 +1032,19 @@ static inline int chol_window_raise_lds_limit()
     std::lock_guard<std::mutex> lock(lds_mutex);
     if (!lds_limit_raised[dev]) {
         const int max_lds = kFusedMaxRows * kXS * (int)sizeof(real);
+        hipFuncAttributes fa;
+        int window_dyn = max_lds;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(chol_window_kernel)) == hipSuccess &&
+            (int)fa.sharedSizeBytes > 0 && (int)fa.sharedSizeBytes < kLdsPerWorkgroup)
+            window_dyn = std::max(max_lds, kLdsPerWorkgroup - (int)fa.sharedSizeBytes - 256);
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_window_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+                                hipFuncAttributeMaxDynamicSharedMemorySize, window_dyn) != hipSuccess) {
+            (void)hipGetLastError();
+            window_dyn = max_lds;
+        }
+        g_window_max_dyn[dev] = window_dyn;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_window_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, window_dyn) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(chol_fused_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
             set_error("cannot raise the dynamic LDS limit of the single-workgroup Cholesky kernels");
@@ -1043,9 +1066,19 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
     if (window <= kFusedMaxRows) {
         VS_TRY(chol_window_raise_lds_limit());
         const int buf_rows = (window + 15) & ~15;
+        // Dense storage: the window shrinks by a panel per step, the first image holds n - 32 rows
+        // and the second n - 64, so systems somewhat wider than kLookaheadMaxRows still keep both
+        // images in LDS (300 unknowns = 50 cameras just fit beside the static arrays).
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int rows_a = (std::max(n - kNB, 16) + 15) & ~15, rows_b = (std::max(n - 2 * kNB, 16) + 15) & ~15;
+        const size_t tight = (size_t)(rows_a + rows_b) * kXS * sizeof(real);
         if (window <= kLookaheadMaxRows)
             hipLaunchKernelGGL(chol_window_kernel, dim3(1), dim3(kCholThreads), (size_t)2 * buf_rows * kXS * sizeof(real), s,
                                A, n, ld, bw, info, Linv, buf_rows, (int64_t)0, (int64_t)0);
+        else if (bw >= n && dev >= 0 && dev < 64 && tight <= (size_t)g_window_max_dyn[dev] && getenv("VS_BA_NO_WIDE_LOOKAHEAD") == nullptr)
+            hipLaunchKernelGGL(chol_window_kernel, dim3(1), dim3(kCholThreads), tight, s,
+                               A, n, ld, bw, info, Linv, rows_a, (int64_t)0, (int64_t)0);
         else
             hipLaunchKernelGGL(chol_fused_kernel, dim3(1), dim3(kCholThreads), (size_t)buf_rows * kXS * sizeof(real), s,
                                A, n, ld, bw, info, Linv);

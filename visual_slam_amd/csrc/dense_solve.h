@@ -1085,6 +1085,7 @@ static inline int cholesky_solve(real *A, real *b, int n, int64_t ld, int bw, in
         const int turns = (window + 127) / 128;
         if (turns <= 1) hipLaunchKernelGGL(chol_trsv_window_kernel<1>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
         else if (turns <= 2) hipLaunchKernelGGL(chol_trsv_window_kernel<2>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
+        else if (turns <= 3) hipLaunchKernelGGL(chol_trsv_window_kernel<3>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
         else hipLaunchKernelGGL(chol_trsv_window_kernel<(kFusedMaxRows + 127) / 128>, dim3(1), dim3(1024), 0, s, A, n, ld, bw, Linv, b);
     } else {
         for (int k0 = 0; k0 < n; k0 += kNB) {
